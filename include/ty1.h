@@ -1,0 +1,162 @@
+/*
+ * ty1.h -- C-ABI of libty1.so: the MI355X (gfx950) tiny-YOLOv1 hot path.
+ *
+ * The reference (AlucardNosferatu/YOLO) is pure Python on TensorFlow/Keras and has no
+ * FFI/plugin layer of its own; each entry point below therefore cites the
+ * reference Python lines whose arithmetic it replaces.  A reference maintainer binds these
+ * with ctypes; yolo_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; ty1_last_error() returns the
+ *    message of the last failing call on the calling thread.  Nothing throws.
+ *  - all tensor pointers are DEVICE pointers (hipMalloc / torch ROCm memory) unless the
+ *    parameter is documented "host".  The library never allocates or frees caller memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *    asynchronous on that stream; the caller synchronises.
+ *  - activations are NHWC float32; conv weights are OHWI ([Cout][3][3][Cin], i.e. the Keras
+ *    HWIO kernel transposed once at load time); the Dense weight is stored transposed,
+ *    [units][ldk] with ldk >= K (row = output unit).
+ */
+#ifndef TY1_H
+#define TY1_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ty1_stream_t;
+
+/* Library ABI version (bumped on any signature change). */
+int ty1_version(void);
+/* Message of the last error on this thread ("" if none). */
+const char *ty1_last_error(void);
+
+/*
+ * HOST helper.  Fold an inference-mode BatchNormalization into per-channel scale/shift:
+ *   scale = gamma / sqrt(var + eps), shift = beta - mean * scale      (eps = 1e-3, Keras default)
+ * Replaces: BatchNormalization(...) layers, /root/reference/models/model_tiny_yolov1.py:45,51,...,86
+ * All pointers are HOST pointers, C floats each.
+ */
+int ty1_fold_bn(const float *gamma, const float *beta, const float *mean, const float *var,
+                float eps, int C, float *scale, float *shift);
+
+/*
+ * y = [maxpool2x2/2]( leaky_relu( conv3x3_same(x, w) * scale + shift, alpha ) )
+ * Replaces one Conv2D(3x3,'same',use_bias=False) + BatchNormalization + LeakyReLU(0.1)
+ * [+ MaxPooling2D((2,2),strides=(2,2))] block: /root/reference/models/model_tiny_yolov1.py:43-87.
+ *   x (N,H,W,Cin) f32 NHWC; w (Cout,3,3,Cin) f32 OHWI; scale/shift (Cout);
+ *   y (N,H/2,W/2,Cout) if pool else (N,H,W,Cout).  pool requires even H and W.
+ *   Cin must be 3 or a multiple of 16; Cout a multiple of 16.
+ */
+int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const float *scale, const float *shift,
+                             float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                             ty1_stream_t stream);
+
+/*
+ * Split-K Dense: part[s][n][u] = sum_{k in slice s} x[n][k] * wt[u][k]      (no bias here)
+ * Replaces the matmul of Flatten + Dense(1470,'linear',name='connected_0'):
+ * /root/reference/models/model_tiny_yolov1.py:89,96.  The bias add and the split-K reduction
+ * are fused into ty1_head_activate_f32.
+ *   x (N,K) f32 (HWC-flattened features); wt (units, ldk) f32, row u = weights of output unit u;
+ *   part (splits, N, ldz) f32 with ldz >= units.  K must be a multiple of 32*splits.
+ */
+int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units,
+                         int ldk, int ldz, int splits, ty1_stream_t stream);
+
+/*
+ * z = sum_s part[s] + bias ; y = concat(softmax_C(z_cls), sigmoid(z_conf), sigmoid(z_box))
+ * Replaces the Dense bias add and ReshapeYOLO.call: /root/reference/models/model_tiny_yolov1.py:14-34
+ * (C=1 twin: /root/reference/faces/trainFace.py:38-58).
+ *   part (splits,N,ldz) planar [S*S*C | S*S*B | S*S*4B]; bias (units) or NULL;
+ *   y (N,S,S,C+5B) f32 [cls C | conf B | box 4B].
+ */
+int ty1_head_activate_f32(const float *part, const float *bias, float *y, int N, int S, int B, int C,
+                          int ldz, int splits, ty1_stream_t stream);
+
+/*
+ * Decode + adaptive score threshold + class-agnostic greedy NMS ("yolo_eval"), per image.
+ * Replaces /root/reference/tiny_yolov1.py:82-140 with YOLO_head :36-55, iou :58-72 and
+ * utils.X_Y_W_H_To_Min_Max /root/reference/utils.py:19-23 (C=1 twin:
+ * /root/reference/faces/testFace.py:51-110).  Bit-exact with the reference: scores in
+ * float32, geometry in float64, ties kept per round, last tied slot in raster order
+ * suppresses, IoU > iou_thr strict, NaN never suppresses.
+ *   pred  (N,S,S,C+5B) f32;            requires S*S <= 64 and 1 <= B <= 4
+ *   boxes (N,S*S*B,4) f64  x0,y0,x1,y1 pixels, zero unless kept      (:139-140)
+ *   score (N,S*S*B) f32    confidence after the first filter          (:112)
+ *   cls   (N,S*S*B) i32    argmax class, zero unless it passed the filter (:107)
+ *   keep  (N,S*S*B) u8     nms_mask
+ */
+int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, double iou_thr,
+                   double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream);
+
+/*
+ * box_xy, box_wh = yolo_head(feats, img_size)   (float32 throughout)
+ * Replaces /root/reference/yolo/yolo.py:23-45.   feats (N,S,S,B,4) -> xy (N,S,S,B,2), wh (N,S,S,B,2).
+ */
+int ty1_yolo_head_f32(const float *feats, float *xy, float *wh, int N, int S, int B, int img_size,
+                      ty1_stream_t stream);
+
+/*
+ * Elementwise IoU of n box pairs (mins/maxes are (n,2) f32).  Replaces /root/reference/yolo/yolo.py:6-20
+ * for equal-shaped operands.
+ */
+int ty1_iou_f32(const float *pred_mins, const float *pred_maxes, const float *true_mins,
+                const float *true_maxes, float *out, int64_t n, ty1_stream_t stream);
+
+/*
+ * YOLOv1 loss forward + closed-form backward.
+ * Replaces /root/reference/yolo/yolo.py:48-107 and the autodiff Keras derives from it
+ * (C=1 twin /root/reference/faces/trainFace.py:66-126, img_size 224).
+ *   y_true (N,S,S,C+5) f32 [one-hot C | x,y,w,h | response]; y_pred (N,S,S,C+5B) f32
+ *   loss_per_image (N) f32; loss (1) f32 = batch SUM (not mean); grad (N,S,S,C+5B) f32 = dL/dy_pred
+ *   (grad may be NULL for forward only).  Requires S*S <= 64, 1 <= B <= 4.
+ */
+int ty1_yolo_loss_fwd_bwd(const float *y_true, const float *y_pred, int N, int S, int B, int C,
+                          int img_size, float *loss_per_image, float *loss, float *grad,
+                          ty1_stream_t stream);
+
+/*
+ * Backward through ReshapeYOLO.call (softmax / sigmoid Jacobians), output in the planar Dense layout:
+ *   dz (N, ldz) f32 from y (N,S,S,C+5B) and grad_y = dL/dy.  Columns >= units are zeroed.
+ * Replaces the autodiff of /root/reference/models/model_tiny_yolov1.py:14-34.
+ */
+int ty1_head_activate_bwd_f32(const float *y, const float *grad_y, float *dz, int N, int S, int B, int C,
+                              int ldz, ty1_stream_t stream);
+
+/*
+ * Dense weight gradient (the only trainable layer):
+ *   dwt[u][k] = sum_n dz[n][u] * x[n][k]   (u < units, k < K),   db[u] = sum_n dz[n][u]
+ * Replaces the autodiff of Dense(1470): /root/reference/models/model_tiny_yolov1.py:96.
+ *   dz (N,ldz); x (N,K); dwt (units, ldk) same layout as the forward weight; db (units).
+ *   K must be a multiple of 64; rows u in [units, ceil32(units)) of dwt are not touched.
+ */
+int ty1_dense_wgrad_f32(const float *dz, const float *x, float *dwt, float *db, int N, int K, int units,
+                        int ldk, int ldz, ty1_stream_t stream);
+
+/*
+ * Adam step, Keras semantics (lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)).
+ * Replaces optimizer Adam(lr=0.001) of /root/reference/train.py:59 (beta .9/.999, eps 1e-7).
+ *   p, g, m, v: n floats each; t = 1-based step count.
+ */
+int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, int64_t t, ty1_stream_t stream);
+
+/*
+ * Per-kernel device timing with HIP events recorded on the launch stream (used by bench.py
+ * for the roofline figure).  ty1_prof_enable(1) makes every later launch of this thread
+ * bracket itself with events; ty1_prof_query synchronises those events and returns the
+ * launch count and summed milliseconds for kernels whose name starts with `prefix`.
+ */
+int ty1_prof_enable(int on);
+int ty1_prof_reset(void);
+int ty1_prof_query(const char *prefix, int *launches, double *total_ms);
+/* Writes up to cap bytes of "name launches total_ms\n" lines for every kernel seen. */
+int ty1_prof_dump(char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TY1_H */

@@ -1,0 +1,251 @@
+"""GPU parity tests: every libty1.so kernel, called through the C-ABI (yolo_amd.ops), against the
+CPU oracle on the same seeded inputs and against the committed reference-generated goldens.
+
+Bars: decode+NMS bit-exact (keep lists, float64 boxes, classes, scores); float kernels within the
+tolerances written next to each assert (north_star: 1e-3 relative for fp32 conv/head outputs)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import model_ref, loss_ref
+from conftest import load_golden
+from yolo_amd import ops, params as P
+from yolo_amd.engine import DeviceModel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def bits64(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def assert_detections_equal(got, want):
+    boxes, score, cls, keep = (t.cpu().numpy() for t in got)
+    assert np.array_equal(keep, want['keep'])
+    assert np.array_equal(cls, want['cls'])
+    assert np.array_equal(score.view(np.uint32), want['score'].view(np.uint32))
+    assert np.array_equal(bits64(boxes), bits64(want['boxes']))
+
+
+# ------------------------------------------------------------------------------- decode + NMS
+@pytest.mark.parametrize('name,C,img', [('nms_c20.npz', 20, 448), ('nms_c1.npz', 1, 224)])
+def test_decode_nms_reference_goldens(name, C, img):
+    g = load_golden(name)
+    pred = g['prediction']
+    got = ops.decode_nms(dev(pred), 2, C, img)
+    boxes, score, cls, keep = (t.cpu().numpy() for t in got)
+    for i in range(pred.shape[0]):                       # what the reference drew, in raster order
+        idx = np.nonzero(keep[i])[0]
+        rects = np.array([[int(v) for v in boxes[i, s]] for s in idx], np.int64).reshape(-1, 4)
+        lo, hi = g['rect_off'][i], g['rect_off'][i + 1]
+        assert np.array_equal(rects, g['rects'][lo:hi]), f'case {i}'
+        if C == 20:
+            assert np.array_equal(cls[i][idx], g['labels'][lo:hi])
+        else:
+            assert [str(np.float32(v)) for v in score[i][idx]] == list(g['conf_str'][lo:hi])
+    assert_detections_equal(got, oracle.decode_nms(pred, 2, C, img))
+
+
+def _synthetic_pred(N, C, seed):
+    rng = np.random.default_rng(seed)
+    D = C + 10
+    p = np.empty((N, 7, 7, D), np.float32)
+    if C > 1:
+        z = 4 * rng.random((N, 7, 7, C))
+        e = np.exp(z - z.max(-1, keepdims=True))
+        p[..., :C] = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    else:
+        p[..., :C] = 1.0
+    p[..., C:C + 2] = rng.random((N, 7, 7, 2)).astype(np.float32)
+    p[..., C + 2:] = rng.random((N, 7, 7, 8)).astype(np.float32)
+    return p
+
+
+@pytest.mark.parametrize('N,C,img', [(1, 20, 448), (64, 20, 448), (1027, 20, 448), (4096, 1, 448)])
+def test_decode_nms_bit_exact_vs_oracle(N, C, img):
+    pred = _synthetic_pred(N, C, seed=2)
+    if N >= 64:                                   # stress: small dense boxes, quantised confidences (ties)
+        pred[N // 2:, ..., C + 2:] *= np.array([1, 1, .15, .15, 1, 1, .15, .15], np.float32)
+        pred[N // 4:N // 2, ..., C:C + 2] = np.round(pred[N // 4:N // 2, ..., C:C + 2] * 8) / 8
+    got = ops.decode_nms(dev(pred), 2, C, img)
+    want = oracle.decode_nms(pred, 2, C, img)
+    assert_detections_equal(got, want)
+    if N == 4096:                                 # size-independent properties at the full config-5 size
+        boxes, score, cls, keep = (t.cpu().numpy() for t in got)
+        assert keep.sum(1).min() >= 1             # the top-confidence box is always kept
+        assert not boxes[keep == 0].any()         # suppressed slots are zeroed
+        again = ops.decode_nms(dev(pred), 2, C, img)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))      # deterministic
+
+
+def test_decode_nms_edge_cases():
+    z = ops.decode_nms(torch.zeros((0, 7, 7, 30), device=DEV), 2, 20, 448)
+    assert z[3].shape == (0, 98)
+    pred = np.zeros((3, 7, 7, 30), np.float32)
+    pred[1] = _synthetic_pred(1, 20, 5)[0]
+    pred[1, 3, 3, 20] = np.nan                    # NaN confidence: np.max is NaN, loop never starts
+    pred[2] = _synthetic_pred(1, 20, 6)[0]
+    pred[2, ..., 24:26] = 0                       # zero-area boxes: 0/0 IoU never suppresses
+    assert_detections_equal(ops.decode_nms(dev(pred), 2, 20, 448), oracle.decode_nms(pred, 2, 20, 448))
+    # other grid / box counts the ABI accepts
+    for S, B, C in [(4, 1, 3), (8, 3, 5), (5, 4, 2)]:
+        rng = np.random.default_rng(S)
+        p = rng.random((9, S, S, C + 5 * B)).astype(np.float32)
+        assert_detections_equal(ops.decode_nms(dev(p), B, C, 320), oracle.decode_nms(p, B, C, 320))
+    with pytest.raises(Exception, match='one wavefront'):
+        ops.decode_nms(torch.zeros((1, 9, 9, 30), device=DEV), 2, 20, 448)
+
+
+# ------------------------------------------------------------------------------- conv blocks
+def _conv_case(N, H, cin, cout, pool, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.random((N, H, H, cin)).astype(np.float32)
+    w = P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)
+    gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    mean = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
+    scale, shift = ops.fold_bn(gamma, beta, mean, var)
+    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool).cpu().numpy()
+    return got, ref
+
+
+LAYERS = [(2, 448, 3, 16, True), (2, 224, 16, 32, True), (2, 112, 32, 64, True), (3, 56, 64, 128, True),
+          (3, 28, 128, 256, True), (5, 14, 256, 512, True), (5, 7, 512, 1024, False), (5, 7, 1024, 256, False),
+          # shapes outside the model: odd tiles / tails / no-pool variants of the early layers
+          (1, 40, 3, 16, False), (1, 36, 3, 32, True), (1, 20, 16, 32, False), (2, 10, 32, 64, True),
+          (1, 6, 64, 128, False), (70, 7, 64, 64, False)]
+
+
+@pytest.mark.parametrize('N,H,cin,cout,pool', LAYERS)
+def test_conv_block_vs_oracle(N, H, cin, cout, pool):
+    got, ref = _conv_case(N, H, cin, cout, pool, seed=cin + cout)
+    assert got.shape == ref.shape
+    # fp32 bar of north_star: 1e-3 relative.  Measured error is ~1e-6 (exact-f32 MFMA, fp32 accumulate).
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-5)
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------- dense + head
+@pytest.mark.parametrize('N,C', [(1, 20), (5, 20), (64, 20), (33, 1)])
+def test_dense_head_vs_oracle(N, C):
+    rng = np.random.default_rng(N)
+    units = 49 * (C + 10)
+    feats = rng.standard_normal((N, P.FEATURES)).astype(np.float32)
+    w = (0.02 * rng.standard_normal((P.FEATURES, units))).astype(np.float32)
+    b = rng.standard_normal(units).astype(np.float32)
+    z_ref = model_ref.dense_ref(feats, w, b)
+    y_ref = model_ref.head_activate_ref(z_ref, 7, 2, C)
+    wt = dev(P.dense_to_device_layout(w))
+    part = ops.dense_splitk(dev(feats), wt, units)
+    z = part.sum(0)[:, :units].cpu().numpy() + b
+    np.testing.assert_allclose(z, z_ref, rtol=1e-3, atol=2e-4)
+    y = ops.head_activate(part, dev(b), 7, 2, C).cpu().numpy()
+    np.testing.assert_allclose(y, y_ref, rtol=1e-3, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- whole model
+@pytest.mark.parametrize('N,C,bn', [(2, 20, 'random'), (1, 1, 'identity')])
+def test_model_end_to_end_vs_oracle(N, C, bn):
+    prm = P.make_random_params(seed=1, C=C, dense_init='spread', bn=bn)
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(0)).numpy()
+    model = DeviceModel(prm, C=C, device=DEV)
+    xd = dev(x)
+    feats = model.backbone(xd).cpu().numpy()
+    feats_ref, acts_ref = model_ref.backbone_ref(x, prm, return_all=True)
+    for a_got, a_ref in zip(model.workspace(N)['acts'], acts_ref):
+        np.testing.assert_allclose(a_got.cpu().numpy(), a_ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(a_ref).max()))
+    np.testing.assert_allclose(feats, feats_ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(feats_ref).max()))
+    y = model.predict(xd).cpu().numpy()
+    y_ref = model_ref.model_ref(x, prm, 7, 2, C)
+    np.testing.assert_allclose(y, y_ref, rtol=1e-3, atol=1e-4)
+    # detections: bit-exact given identical scores (the oracle is fed the GPU's own y)
+    got = model.detect(xd)
+    assert_detections_equal(got, oracle.decode_nms(y, 2, C, 448))
+
+
+# ------------------------------------------------------------------------------- loss
+@pytest.mark.parametrize('name,C', [('loss_c20.npz', 20), ('loss_c1.npz', 1)])
+def test_yolo_loss_vs_reference_goldens(name, C):
+    g = load_golden(name)
+    img = int(g['img_size'])
+    loss, per, grad = ops.yolo_loss_fwd_bwd(dev(g['y_true']), dev(g['y_pred']), 2, C, img)
+    assert abs(loss.item() - g['loss']) <= 1e-5 * abs(g['loss'])
+    np.testing.assert_allclose(per.cpu().numpy(), g['loss_per_image'], rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g['grad'], rtol=1e-4, atol=1e-6)
+    boxes = dev(g['y_pred'][..., C + 2:]).reshape(-1, 7, 7, 2, 4).contiguous()
+    xy, wh = ops.yolo_head(boxes, img)
+    assert np.array_equal(xy.cpu().numpy(), g['head_xy']) and np.array_equal(wh.cpu().numpy(), g['head_wh'])
+    mins, maxes = xy - wh / 2, xy + wh / 2
+    ious = ops.iou(mins[:, :, :, 0], maxes[:, :, :, 0], mins[:, :, :, 1], maxes[:, :, :, 1])
+    np.testing.assert_allclose(ious.cpu().numpy(), g['iou_b0_b1'], rtol=1e-6, atol=0)
+
+
+def test_yolo_loss_batch_vs_oracle():
+    rng = np.random.default_rng(3)
+    N, C = 32, 20
+    y_true = np.zeros((N, 7, 7, 25), np.float32)
+    for n in range(N):
+        for _ in range(3):
+            r, c, k = rng.integers(0, 7), rng.integers(0, 7), rng.integers(0, C)
+            if y_true[n, r, c, 24] == 0:
+                y_true[n, r, c, k] = 1
+                y_true[n, r, c, 20:24] = rng.random(4)
+                y_true[n, r, c, 24] = 1
+    z = rng.standard_normal((N, 1470)).astype(np.float32)
+    y_pred = model_ref.head_activate_ref(z)
+    loss_ref_, per_ref, grad_ref = loss_ref.yolo_loss_and_grad_ref(y_true, y_pred)
+    loss, per, grad = ops.yolo_loss_fwd_bwd(dev(y_true), dev(y_pred))
+    assert abs(loss.item() - loss_ref_) <= 1e-5 * abs(loss_ref_)
+    np.testing.assert_allclose(grad.cpu().numpy(), grad_ref, rtol=1e-4, atol=1e-6)
+    # batch SUM: the loss of the batch equals the sum of its halves
+    la, _, _ = ops.yolo_loss_fwd_bwd(dev(y_true[:16]), dev(y_pred[:16]))
+    lb, _, _ = ops.yolo_loss_fwd_bwd(dev(y_true[16:]), dev(y_pred[16:]))
+    assert abs(la.item() + lb.item() - loss.item()) <= 1e-5 * abs(loss.item())
+
+
+# ------------------------------------------------------------------------------- training kernels
+def test_head_backward_wgrad_adam_vs_torch():
+    rng = np.random.default_rng(4)
+    N, C, units = 32, 20, 1470
+    feats = rng.standard_normal((N, P.FEATURES)).astype(np.float32)
+    z = rng.standard_normal((N, units)).astype(np.float32)
+    gy = rng.standard_normal((N, 7, 7, 30)).astype(np.float32)
+    # torch fp32 reference of the head Jacobian and dW = x^T dz
+    zt = torch.from_numpy(z).requires_grad_(True)
+    i1, i2 = 49 * C, 49 * C + 98
+    y_t = torch.cat([torch.softmax(zt[:, :i1].reshape(N, 7, 7, C), -1), torch.sigmoid(zt[:, i1:i2].reshape(N, 7, 7, 2)),
+                     torch.sigmoid(zt[:, i2:].reshape(N, 7, 7, 8))], -1)
+    (y_t * torch.from_numpy(gy)).sum().backward()
+    dz_ref = zt.grad.numpy()
+    ldz = ops.round_up(units, 4)
+    dz = ops.head_activate_bwd(dev(y_t.detach().numpy()), dev(gy), ldz)
+    np.testing.assert_allclose(dz.cpu().numpy()[:, :units], dz_ref, rtol=1e-4, atol=1e-6)
+    rows = ops.round_up(units, 32)
+    dwt = torch.zeros((rows, P.FEATURES), device=DEV)
+    db = torch.zeros((units,), device=DEV)
+    ops.dense_wgrad(dz, dev(feats), units, dwt, db)
+    dw_ref = (torch.from_numpy(dz_ref).t().double() @ torch.from_numpy(feats).double()).numpy()
+    np.testing.assert_allclose(dwt.cpu().numpy()[:units], dw_ref, rtol=1e-3, atol=1e-4)
+    assert not dwt[units:].any()
+    np.testing.assert_allclose(db.cpu().numpy(), dz_ref.sum(0), rtol=1e-4, atol=1e-5)
+    # Adam, Keras semantics, three steps against a float64 restatement
+    n = 100003
+    p = rng.standard_normal(n).astype(np.float32)
+    pd, md, vd = dev(p.copy()[:100000]), torch.zeros(100000, device=DEV), torch.zeros(100000, device=DEV)
+    pr, mr, vr = p[:100000].astype(np.float64), np.zeros(100000), np.zeros(100000)
+    for t in range(1, 4):
+        g = rng.standard_normal(100000).astype(np.float32)
+        ops.adam_step(pd, dev(g), md, vd, t)
+        mr = 0.9 * mr + 0.1 * g
+        vr = 0.999 * vr + 0.001 * g.astype(np.float64) ** 2
+        pr = pr - 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * mr / (np.sqrt(vr) + 1e-7)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,37 @@
+// Shared host-side helpers of libty1.so: error reporting, launch checks, event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/ty1.h"
+
+namespace ty1 {
+
+std::string &last_error();
+int fail(const char *fmt, ...);
+
+// Event bracket around one kernel launch (only when profiling is enabled on this thread).
+struct ProfScope {
+    ProfScope(const char *name, hipStream_t s);
+    ~ProfScope();
+    const char *name;
+    hipStream_t stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on;
+};
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace ty1
+
+#define TY1_REQUIRE(cond, ...)                       \
+    do {                                             \
+        if (!(cond)) return ty1::fail(__VA_ARGS__);  \
+    } while (0)

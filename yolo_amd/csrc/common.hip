@@ -1,0 +1,123 @@
+// libty1.so: error state, BN folding (host), per-kernel event profiling.
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace ty1 {
+
+std::string &last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return 1;
+}
+
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    int launches = 0;
+    double ms = 0.0;
+};
+static thread_local bool g_prof_on = false;
+static thread_local std::map<std::string, ProfEntry> g_prof;
+
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), on(g_prof_on) {
+    if (!on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        on = false;
+        return;
+    }
+    (void)hipEventRecord(e0, stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, stream);
+    g_prof[name].pending.emplace_back(e0, e1);
+}
+
+static void prof_collect() {
+    for (auto &kv : g_prof) {
+        for (auto &p : kv.second.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+                kv.second.ms += ms;
+                kv.second.launches += 1;
+            }
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+}  // namespace ty1
+
+extern "C" {
+
+int ty1_version(void) { return 1; }
+
+const char *ty1_last_error(void) { return ty1::last_error().c_str(); }
+
+int ty1_fold_bn(const float *gamma, const float *beta, const float *mean, const float *var, float eps, int C,
+                float *scale, float *shift) {
+    TY1_REQUIRE(gamma && beta && mean && var && scale && shift && C > 0, "ty1_fold_bn: bad arguments");
+    for (int c = 0; c < C; ++c) {
+        float s = gamma[c] / std::sqrt(var[c] + eps);
+        scale[c] = s;
+        shift[c] = beta[c] - mean[c] * s;
+    }
+    return 0;
+}
+
+int ty1_prof_enable(int on) {
+    ty1::g_prof_on = on != 0;
+    return 0;
+}
+
+int ty1_prof_reset(void) {
+    ty1::prof_collect();
+    ty1::g_prof.clear();
+    return 0;
+}
+
+int ty1_prof_query(const char *prefix, int *launches, double *total_ms) {
+    TY1_REQUIRE(prefix && launches && total_ms, "ty1_prof_query: null argument");
+    ty1::prof_collect();
+    int n = 0;
+    double ms = 0;
+    size_t len = strlen(prefix);
+    for (auto &kv : ty1::g_prof)
+        if (kv.first.compare(0, len, prefix) == 0) {
+            n += kv.second.launches;
+            ms += kv.second.ms;
+        }
+    *launches = n;
+    *total_ms = ms;
+    return 0;
+}
+
+int ty1_prof_dump(char *buf, size_t cap) {
+    TY1_REQUIRE(buf && cap > 0, "ty1_prof_dump: bad buffer");
+    ty1::prof_collect();
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto &kv : ty1::g_prof) {
+        int w = snprintf(buf + off, cap - off, "%s %d %.6f\n", kv.first.c_str(), kv.second.launches, kv.second.ms);
+        if (w < 0 || (size_t)w >= cap - off) break;
+        off += (size_t)w;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// Decode + adaptive threshold + class-agnostic greedy NMS: one 64-lane wavefront per image,
+// one lane per grid cell (S*S <= 64), B boxes per lane in registers.
+//
+// Mirrors /root/reference/tiny_yolov1.py:82-140 (C=1 twin faces/testFace.py:51-110) bit for bit:
+// scores/confidences in float32, box geometry in float64, ">= best" responsible-box
+// ties, "max/2" adaptive threshold, per-round confidence ties all kept with the LAST tied slot in
+// raster order as the suppressor (Q4), IoU > thr strict so NaN never suppresses.
+//
+// The image's C+5B head rows are staged through LDS with coalesced loads; every reduction is a
+// 64-lane butterfly (no block barrier inside the greedy loop); the suppressor box is broadcast
+// with readlane-style shuffles.  HBM-bound by construction: 4*(C+5B)*S*S bytes in, 41*S*S*B out.
+//
+// Strict IEEE arithmetic is required for bit-exact parity: this file is compiled with
+// -ffp-contract=off and uses no fast-math.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float np_maxf(float a, float b) {      // np.max: NaN propagates
+    if (a != a) return a;
+    if (b != b) return b;
+    return a >= b ? a : b;
+}
+
+__device__ __forceinline__ float wave_np_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = np_maxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// tiny_yolov1.py:58-72 in float64; np.maximum/np.minimum propagate NaN.
+__device__ __forceinline__ double iou_f64(const double amin[2], const double amax[2], const double bmin[2],
+                                          const double bmax[2]) {
+    double wh[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        double hi = amax[d] < bmax[d] ? amax[d] : bmax[d];
+        double lo = amin[d] > bmin[d] ? amin[d] : bmin[d];
+        double v = hi - lo;
+        bool nan = (amin[d] != amin[d]) || (bmin[d] != bmin[d]) || (amax[d] != amax[d]) || (bmax[d] != bmax[d]);
+        if (nan) v = __builtin_nan("");
+        else if (!(v > 0.)) v = 0.;
+        wh[d] = v;
+    }
+    double inter = wh[0] * wh[1];
+    double pa = (amax[0] - amin[0]) * (amax[1] - amin[1]);
+    double ta = (bmax[0] - bmin[0]) * (bmax[1] - bmin[1]);
+    double uni = pa + ta - inter;
+    return inter / uni;
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict__ pred, int N, int S, int C,
+                                                          int img_size, double iou_thr, int img_stride, int vec2,
+                                                          double *__restrict__ boxes, float *__restrict__ score,
+                                                          int32_t *__restrict__ cls, uint8_t *__restrict__ keep) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    const bool active = n < N;
+    const int cells = S * S, D = C + 5 * B, slots = cells * B, total = cells * D;
+    float *img = lds + wave * img_stride;
+
+    if (active) {
+        const float *src = pred + (size_t)n * total;
+        // 8-byte loads when every image base is 8-byte aligned (checked on the host)
+        if (vec2) {
+            const float2 *s2 = reinterpret_cast<const float2 *>(src);
+            float2 *d2 = reinterpret_cast<float2 *>(img);
+            for (int i = lane; i < total / 2; i += 64) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += 64) img[i] = src[i];
+        }
+    }
+    __syncthreads();
+
+    const bool valid = active && lane < cells;
+    const float *pc = img + (valid ? lane : 0) * D;
+    const float NEG_INF = -__builtin_inff();
+
+    float bcs[B], trust[B];
+    int bcl[B];
+    bool filt[B], kept[B];
+    double mn[B][2], mx[B][2];
+
+    // :90-93 scores = class * trust, first argmax and max over classes (NumPy argmax NaN rule)
+    float cell_best = NEG_INF;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        float mp = NEG_INF;
+        int mi = 0;
+        if (valid) {
+            float t = pc[C + k];
+            mp = pc[0] * t;
+            if (mp == mp) {
+                for (int m = 1; m < C; ++m) {
+                    float v = pc[m] * t;
+                    if (!(v <= mp)) {
+                        mp = v;
+                        mi = m;
+                        if (mp != mp) break;
+                    }
+                }
+            }
+        }
+        bcs[k] = mp;
+        bcl[k] = mi;
+        cell_best = (k == 0) ? mp : np_maxf(cell_best, mp);
+        kept[k] = false;
+    }
+    // :94-99 responsible box(es) of the cell and the adaptive threshold max/2
+    const float gmax = wave_np_max(cell_best);
+    const float thr = gmax / 2;
+    const int r = lane / S, c = lane - r * S;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        filt[k] = valid && (bcs[k] >= thr) && (bcs[k] >= cell_best);
+        // :103-112 zero what is filtered, decode (YOLO_head xy in f64, wh in f32; min/max in f64)
+        const float f = filt[k] ? 1.0f : 0.0f;
+        const float *pb = pc + C + B + 4 * k;
+        float bx = pb[0] * f, by = pb[1] * f, bw = pb[2] * f, bh = pb[3] * f;
+        double x = ((double)bx + (double)c) / (double)S * (double)img_size;
+        double y = ((double)by + (double)r) / (double)S * (double)img_size;
+        float w = bw * (float)img_size, h = bh * (float)img_size;
+        float hw = w / 2, hh = h / 2;
+        mn[k][0] = x - (double)hw;
+        mn[k][1] = y - (double)hh;
+        mx[k][0] = x + (double)hw;
+        mx[k][1] = y + (double)hh;
+        trust[k] = valid ? pc[C + k] * f : NEG_INF;
+        bcl[k] = filt[k] ? bcl[k] : 0;
+        if (valid) {
+            score[(size_t)n * slots + lane * B + k] = trust[k];
+            cls[(size_t)n * slots + lane * B + k] = bcl[k];
+        }
+    }
+
+    // :113-137 greedy loop.  Every round clears at least one slot, so it ends within `slots` rounds.
+    float lmax = trust[0];
+#pragma unroll
+    for (int k = 1; k < B; ++k) lmax = np_maxf(lmax, trust[k]);
+    float tmax = wave_np_max(lmax);
+    for (int round = 0; round < slots && tmax > 0; ++round) {
+        int my_last = -1;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (trust[k] == tmax) {
+                kept[k] = true;
+                filt[k] = false;
+                my_last = lane * B + k;
+            }
+        }
+        const int last = wave_max_i(my_last);          // last tied slot in raster order
+        const int owner = last / B, kl = last - owner * B;
+        double smin[2], smax[2], sel[4];
+        sel[0] = mn[0][0]; sel[1] = mn[0][1]; sel[2] = mx[0][0]; sel[3] = mx[0][1];
+#pragma unroll
+        for (int k = 1; k < B; ++k)
+            if (kl == k) { sel[0] = mn[k][0]; sel[1] = mn[k][1]; sel[2] = mx[k][0]; sel[3] = mx[k][1]; }
+        smin[0] = __shfl(sel[0], owner, 64);
+        smin[1] = __shfl(sel[1], owner, 64);
+        smax[0] = __shfl(sel[2], owner, 64);
+        smax[1] = __shfl(sel[3], owner, 64);
+        lmax = NEG_INF;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (filt[k]) {
+                double v = iou_f64(smin, smax, mn[k], mx[k]);
+                if (v > iou_thr) filt[k] = false;
+            }
+            if (valid) trust[k] = trust[k] * (filt[k] ? 1.0f : 0.0f);
+            lmax = (k == 0) ? trust[k] : np_maxf(lmax, trust[k]);
+        }
+        tmax = wave_np_max(lmax);
+    }
+
+    // :139-140
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const double m = kept[k] ? 1.0 : 0.0;
+            double *o = boxes + ((size_t)n * slots + lane * B + k) * 4;
+            double2 lo = make_double2(mn[k][0] * m, mn[k][1] * m);
+            double2 hi = make_double2(mx[k][0] * m, mx[k][1] * m);
+            reinterpret_cast<double2 *>(o)[0] = lo;
+            reinterpret_cast<double2 *>(o)[1] = hi;
+            keep[(size_t)n * slots + lane * B + k] = kept[k] ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, double iou_thr,
+                              double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && C > 0 && img_size > 0, "ty1_decode_nms: bad dimensions N=%d S=%d C=%d", N, S, C);
+    TY1_REQUIRE(S * S <= 64, "ty1_decode_nms: S*S=%d exceeds one wavefront (64 cells)", S * S);
+    TY1_REQUIRE(B >= 1 && B <= 4, "ty1_decode_nms: B=%d not in 1..4", B);
+    if (N == 0) return 0;
+    TY1_REQUIRE(pred && boxes && score && cls && keep, "ty1_decode_nms: null pointer");
+    const int total = S * S * (C + 5 * B);
+    const int img_stride = (total + 1) & ~1;
+    const size_t lds = (size_t)4 * img_stride * sizeof(float);
+    TY1_REQUIRE(lds <= 64 * 1024, "ty1_decode_nms: C=%d needs %zu bytes of LDS (max 65536)", C, lds);
+    const int vec2 = ((total & 1) == 0 && ((uintptr_t)pred & 7) == 0) ? 1 : 0;
+    TY1_REQUIRE(((uintptr_t)boxes & 15) == 0, "ty1_decode_nms: boxes must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((N + 3) / 4), block(256);
+    ty1::ProfScope prof("decode_nms", s);
+    switch (B) {
+        case 1: decode_nms_kernel<1><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
+        case 2: decode_nms_kernel<2><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
+        case 3: decode_nms_kernel<3><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
+        default: decode_nms_kernel<4><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
+    }
+    return ty1::check_launch("ty1_decode_nms");
+}

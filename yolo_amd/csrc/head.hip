@@ -1,0 +1,98 @@
+// Head activations (ReshapeYOLO.call) fused with the Dense split-K reduction and bias add, and the
+// matching backward (softmax / sigmoid Jacobians).
+// Replaces /root/reference/models/model_tiny_yolov1.py:14-34 (C=1 twin faces/trainFace.py:38-58).
+//
+// Layouts: Dense output is PLANAR: z[0 : S*S*C] -> (S,S,C), z[S*S*C : +S*S*B] -> (S,S,B),
+// rest -> (S,S,4B); the activated tensor is cell-major (N,S,S,C+5B) = [cls C | conf B | box 4B].
+// One block per image; z is reduced over the split-K partials into LDS once.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void head_activate_kernel(const float *__restrict__ part,
+                                                             const float *__restrict__ bias, float *__restrict__ y,
+                                                             int N, int S, int B, int C, int ldz, int splits) {
+    extern __shared__ float z[];
+    const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
+    for (int u = threadIdx.x; u < units; u += blockDim.x) {
+        float acc = bias ? bias[u] : 0.f;
+        for (int s = 0; s < splits; ++s) acc += part[((size_t)s * N + n) * ldz + u];
+        z[u] = acc;
+    }
+    __syncthreads();
+    float *out = y + (size_t)n * units;
+    const int i1 = cells * C, i2 = i1 + cells * B;
+    // softmax over the C classes of one cell: one thread per cell
+    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
+        const float *zc = z + cell * C;
+        float mx = zc[0];
+        for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
+        float sum = 0.f;
+        for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
+        const float inv = 1.0f / sum;
+        for (int m = 0; m < C; ++m) out[cell * D + m] = expf(zc[m] - mx) * inv;
+    }
+    for (int i = threadIdx.x; i < cells * B; i += blockDim.x) {
+        const int cell = i / B, k = i - cell * B;
+        out[cell * D + C + k] = sigmoidf_(z[i1 + i]);
+    }
+    for (int i = threadIdx.x; i < cells * 4 * B; i += blockDim.x) {
+        const int cell = i / (4 * B), k = i - cell * (4 * B);
+        out[cell * D + C + B + k] = sigmoidf_(z[i2 + i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_activate_bwd_kernel(const float *__restrict__ y,
+                                                                 const float *__restrict__ gy, float *__restrict__ dz,
+                                                                 int N, int S, int B, int C, int ldz) {
+    const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
+    const float *yn = y + (size_t)n * units, *gn = gy + (size_t)n * units;
+    float *dn = dz + (size_t)n * ldz;
+    const int i1 = cells * C, i2 = i1 + cells * B;
+    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
+        float dot = 0.f;
+        for (int m = 0; m < C; ++m) dot += gn[cell * D + m] * yn[cell * D + m];
+        for (int m = 0; m < C; ++m) dn[cell * C + m] = yn[cell * D + m] * (gn[cell * D + m] - dot);
+    }
+    for (int i = threadIdx.x; i < cells * B; i += blockDim.x) {
+        const int cell = i / B, k = i - cell * B;
+        const float s = yn[cell * D + C + k];
+        dn[i1 + i] = gn[cell * D + C + k] * s * (1.f - s);
+    }
+    for (int i = threadIdx.x; i < cells * 4 * B; i += blockDim.x) {
+        const int cell = i / (4 * B), k = i - cell * (4 * B);
+        const float s = yn[cell * D + C + B + k];
+        dn[i2 + i] = gn[cell * D + C + B + k] * s * (1.f - s);
+    }
+    for (int u = units + threadIdx.x; u < ldz; u += blockDim.x) dn[u] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int ty1_head_activate_f32(const float *part, const float *bias, float *y, int N, int S, int B, int C,
+                                     int ldz, int splits, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && B > 0 && C > 0 && splits > 0, "ty1_head_activate: bad dimensions");
+    if (N == 0) return 0;
+    const int units = S * S * (C + 5 * B);
+    TY1_REQUIRE(part && y, "ty1_head_activate: null pointer");
+    TY1_REQUIRE(ldz >= units, "ty1_head_activate: ldz=%d < units=%d", ldz, units);
+    TY1_REQUIRE((size_t)units * 4 <= 64 * 1024, "ty1_head_activate: %d units exceed the LDS budget", units);
+    hipStream_t s = (hipStream_t)stream;
+    ty1::ProfScope prof("head_activate", s);
+    head_activate_kernel<<<dim3(N), dim3(256), (size_t)units * 4, s>>>(part, bias, y, N, S, B, C, ldz, splits);
+    return ty1::check_launch("ty1_head_activate_f32");
+}
+
+extern "C" int ty1_head_activate_bwd_f32(const float *y, const float *grad_y, float *dz, int N, int S, int B, int C,
+                                         int ldz, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && B > 0 && C > 0, "ty1_head_activate_bwd: bad dimensions");
+    if (N == 0) return 0;
+    TY1_REQUIRE(y && grad_y && dz, "ty1_head_activate_bwd: null pointer");
+    TY1_REQUIRE(ldz >= S * S * (C + 5 * B), "ty1_head_activate_bwd: ldz too small");
+    hipStream_t s = (hipStream_t)stream;
+    ty1::ProfScope prof("head_activate_bwd", s);
+    head_activate_bwd_kernel<<<dim3(N), dim3(256), 0, s>>>(y, grad_y, dz, N, S, B, C, ldz);
+    return ty1::check_launch("ty1_head_activate_bwd_f32");
+}

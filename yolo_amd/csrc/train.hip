@@ -1,0 +1,130 @@
+// Training-side kernels of the only trainable layer (Dense 'connected_0'):
+//   weight gradient dWt = dz^T . x on the exact-f32 matrix cores, bias gradient, and the Adam step.
+// Replaces the Keras autodiff of /root/reference/models/model_tiny_yolov1.py:96 and
+// Adam(lr=0.001) of /root/reference/train.py:59.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// GEMM view: M = units (u), N = K features (k), reduction over the batch (tiny: 32 per GPU).
+// The reduction dimension is so short that both MFMA operands are read straight from global memory
+// (dz row b: 32 consecutive u per half-wave, x row b: 32 consecutive k: both 128-byte segments);
+// the kernel is bound by the 73.8 MB dWt store.  Block = 4 waves (2x2), wave = 2x2 tiles of 32x32.
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restrict__ dz, const float *__restrict__ x,
+                                                          float *__restrict__ dwt, int N, int K, int units, int ldk,
+                                                          int ldz) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wu = wave >> 1, wk = wave & 1;
+    const int u0 = blockIdx.y * 128 + wu * 64, k0 = blockIdx.x * 128 + wk * 64;
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool uok0 = u0 + i < units, uok1 = u0 + 32 + i < units;
+    const bool kok0 = k0 + i < K, kok1 = k0 + 32 + i < K;
+    for (int b = h; b < N + h; b += 2) {       // both half-waves run the same trip count
+        const bool bok = b < N;
+        const float *dzr = dz + (size_t)b * ldz + u0 + i;
+        const float *xr = x + (size_t)b * K + k0 + i;
+        const float a0 = (bok && uok0) ? dzr[0] : 0.f, a1 = (bok && uok1) ? dzr[32] : 0.f;
+        const float b0 = (bok && kok0) ? xr[0] : 0.f, b1 = (bok && kok1) ? xr[32] : 0.f;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int k = k0 + 32 * b + i;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = u0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (u < units) dwt[(size_t)u * ldk + k] = acc[a][b][r];
+            }
+        }
+}
+
+__global__ void dense_bgrad_kernel(const float *__restrict__ dz, float *__restrict__ db, int N, int units, int ldz) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc += dz[(size_t)n * ldz + u];
+    db[u] = acc;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, long long n,
+                                                   float lr_t, float b1, float b2, float eps) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+#define TY1_ADAM(c)                                       \
+    mm.c = b1 * mm.c + (1.f - b1) * gg.c;                 \
+    vv.c = b2 * vv.c + (1.f - b2) * (gg.c * gg.c);        \
+    pp.c = pp.c - lr_t * mm.c / (sqrtf(vv.c) + eps);
+        TY1_ADAM(x) TY1_ADAM(y) TY1_ADAM(z) TY1_ADAM(w)
+#undef TY1_ADAM
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int ty1_dense_wgrad_f32(const float *dz, const float *x, float *dwt, float *db, int N, int K, int units,
+                                   int ldk, int ldz, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && K > 0 && units > 0, "ty1_dense_wgrad: bad dimensions");
+    TY1_REQUIRE(dz && x && dwt && db, "ty1_dense_wgrad: null pointer");
+    TY1_REQUIRE(ldk >= K && ldz >= units, "ty1_dense_wgrad: leading dimensions too small");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ty1::ProfScope prof("dense_wgrad", s);
+        dim3 grid((K + 127) / 128, (units + 127) / 128);
+        dense_wgrad_kernel<<<grid, dim3(256), 0, s>>>(dz, x, dwt, N, K, units, ldk, ldz);
+    }
+    if (int rc = ty1::check_launch("ty1_dense_wgrad_f32")) return rc;
+    {
+        ty1::ProfScope prof("dense_bgrad", s);
+        dense_bgrad_kernel<<<dim3((units + 255) / 256), dim3(256), 0, s>>>(dz, db, N, units, ldz);
+    }
+    return ty1::check_launch("ty1_dense_wgrad_f32(bias)");
+}
+
+extern "C" int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, int64_t t, ty1_stream_t stream) {
+    TY1_REQUIRE(n >= 0 && t >= 1, "ty1_adam_step: bad n=%lld or t=%lld", (long long)n, (long long)t);
+    if (n == 0) return 0;
+    TY1_REQUIRE(p && g && m && v, "ty1_adam_step: null pointer");
+    TY1_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "ty1_adam_step: pointers must be 16-byte aligned");
+    // Keras: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    ty1::ProfScope prof("adam_step", s);
+    adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p, g, m, v, n, (float)lr_t, beta1, beta2, eps);
+    return ty1::check_launch("ty1_adam_step_f32");
+}

@@ -1,0 +1,201 @@
+"""Thin host wrappers: torch ROCm tensors are used only as device buffers; every op below is one
+call into libty1.so (hand-written gfx950 kernels) on the current torch stream."""
+import torch
+
+from . import _lib
+
+DENSE_K_ALIGN = 32
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f'{name}: expected a tensor on the GPU (ROCm device)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+    return t
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def fold_bn(gamma, beta, mean, var, eps=1e-3):
+    """NumPy (host) in/out: scale, shift of an inference BatchNormalization (Keras eps 1e-3)."""
+    import numpy as np
+    g, b, m, v = (np.ascontiguousarray(a, np.float32) for a in (gamma, beta, mean, var))
+    scale = np.empty_like(g)
+    shift = np.empty_like(g)
+    _lib.call('ty1_fold_bn', g.ctypes.data, b.ctypes.data, m.ctypes.data, v.ctypes.data,
+              float(eps), int(g.shape[0]), scale.ctypes.data, shift.ctypes.data)
+    return scale, shift
+
+
+def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None):
+    """x (N,H,W,Cin) NHWC f32 -> (N,H/2,W/2,Cout) if pool else (N,H,W,Cout)."""
+    _chk(x, torch.float32, 'x'); _chk(w_ohwi, torch.float32, 'w')
+    _chk(scale, torch.float32, 'scale'); _chk(shift, torch.float32, 'shift')
+    N, H, W, Cin = x.shape
+    Cout = w_ohwi.shape[0]
+    assert tuple(w_ohwi.shape) == (Cout, 3, 3, Cin), w_ohwi.shape
+    oshape = (N, H // 2, W // 2, Cout) if pool else (N, H, W, Cout)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    else:
+        _chk(out, torch.float32, 'out')
+        assert tuple(out.shape) == oshape
+    _lib.call('ty1_conv3x3_bn_leaky_f32', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), _lib.current_stream())
+    return out
+
+
+def pick_splits(K, n_rows, units):
+    """Split-K factor for the Dense GEMM: enough blocks to fill 256 CUs, K/32 divisible."""
+    chunks = K // DENSE_K_ALIGN
+    tiles = ((n_rows + 63) // 64) * ((units + 63) // 64) if n_rows > 32 else (units + 127) // 128
+    best = 1
+    for s in range(1, chunks + 1):
+        if chunks % s == 0 and tiles * s <= 1024:
+            best = s
+    return best
+
+
+def dense_splitk(x, wt, units, splits=None, part=None):
+    """x (N,K) f32, wt (rows>=units, ldk) f32 transposed Dense weight -> partials (splits,N,ldz)."""
+    _chk(x, torch.float32, 'x'); _chk(wt, torch.float32, 'wt')
+    N, K = x.shape
+    ldk = wt.shape[1]
+    if splits is None:
+        splits = pick_splits(K, N, units)
+    ldz = round_up(units, 4)
+    if part is None:
+        part = torch.empty((splits, N, ldz), dtype=torch.float32, device=x.device)
+    else:
+        _chk(part, torch.float32, 'part')
+        splits, _, ldz = part.shape
+    _lib.call('ty1_dense_splitk_f32', x.data_ptr(), wt.data_ptr(), part.data_ptr(), N, K, units, ldk, ldz,
+              splits, _lib.current_stream())
+    return part
+
+
+def head_activate(part, bias, S=7, B=2, C=20, out=None):
+    """partials (splits,N,ldz) [+ bias (units)] -> y (N,S,S,C+5B) = [softmax C | sigmoid B | sigmoid 4B]."""
+    _chk(part, torch.float32, 'part')
+    if part.dim() == 2:
+        part = part.unsqueeze(0)
+    splits, N, ldz = part.shape
+    if bias is not None:
+        _chk(bias, torch.float32, 'bias')
+    if out is None:
+        out = torch.empty((N, S, S, C + 5 * B), dtype=torch.float32, device=part.device)
+    _lib.call('ty1_head_activate_f32', part.data_ptr(), _lib.ptr(bias), out.data_ptr(), N, S, B, C, ldz, splits,
+              _lib.current_stream())
+    return out
+
+
+def decode_nms(pred, B=2, C=20, img_size=448, iou_thr=0.2, out=None):
+    """pred (N,S,S,C+5B) f32 -> boxes (N,S*S*B,4) f64, score (N,S*S*B) f32, cls i32, keep u8."""
+    _chk(pred, torch.float32, 'pred')
+    if pred.dim() == 3:
+        pred = pred.unsqueeze(0)
+    N, S = pred.shape[0], pred.shape[1]
+    if pred.shape[2] != S or pred.shape[3] != C + 5 * B:
+        raise ValueError(f'pred shape {tuple(pred.shape)} does not match S,S,C+5B with B={B}, C={C}')
+    slots = S * S * B
+    if out is None:
+        dev = pred.device
+        out = (torch.empty((N, slots, 4), dtype=torch.float64, device=dev),
+               torch.empty((N, slots), dtype=torch.float32, device=dev),
+               torch.empty((N, slots), dtype=torch.int32, device=dev),
+               torch.empty((N, slots), dtype=torch.uint8, device=dev))
+    boxes, score, cls, keep = out
+    _lib.call('ty1_decode_nms', pred.data_ptr(), N, S, B, C, int(img_size), float(iou_thr),
+              boxes.data_ptr(), score.data_ptr(), cls.data_ptr(), keep.data_ptr(), _lib.current_stream())
+    return boxes, score, cls, keep
+
+
+def yolo_head(feats, img_size=448):
+    _chk(feats, torch.float32, 'feats')
+    if feats.dim() != 5 or feats.shape[-1] != 4 or feats.shape[1] != feats.shape[2]:
+        raise ValueError(f'feats must be (N,S,S,B,4), got {tuple(feats.shape)}')
+    N, S, _, B, _ = feats.shape
+    xy = torch.empty((N, S, S, B, 2), dtype=torch.float32, device=feats.device)
+    wh = torch.empty_like(xy)
+    _lib.call('ty1_yolo_head_f32', feats.data_ptr(), xy.data_ptr(), wh.data_ptr(), N, S, B, int(img_size),
+              _lib.current_stream())
+    return xy, wh
+
+
+def iou(pred_mins, pred_maxes, true_mins, true_maxes):
+    shape = torch.broadcast_shapes(pred_mins.shape, pred_maxes.shape, true_mins.shape, true_maxes.shape)
+    ops = [_chk(t.expand(shape).contiguous(), torch.float32, 'iou operand')
+           for t in (pred_mins, pred_maxes, true_mins, true_maxes)]
+    if shape[-1] != 2:
+        raise ValueError('last axis must be (x, y)')
+    out = torch.empty(shape[:-1], dtype=torch.float32, device=ops[0].device)
+    _lib.call('ty1_iou_f32', *(o.data_ptr() for o in ops), out.data_ptr(), out.numel(), _lib.current_stream())
+    return out
+
+
+def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True):
+    """-> loss (1,) f32 batch SUM, loss_per_image (N,), grad (N,S,S,C+5B) or None."""
+    _chk(y_true, torch.float32, 'y_true'); _chk(y_pred, torch.float32, 'y_pred')
+    N, S = y_pred.shape[0], y_pred.shape[1]
+    if tuple(y_true.shape) != (N, S, S, C + 5) or tuple(y_pred.shape) != (N, S, S, C + 5 * B):
+        raise ValueError(f'shapes {tuple(y_true.shape)} / {tuple(y_pred.shape)} do not match B={B}, C={C}')
+    dev = y_pred.device
+    per = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(y_pred) if want_grad else None
+    _lib.call('ty1_yolo_loss_fwd_bwd', y_true.data_ptr(), y_pred.data_ptr(), N, S, B, C, int(img_size),
+              per.data_ptr(), loss.data_ptr(), _lib.ptr(grad), _lib.current_stream())
+    return loss, per[:N], grad
+
+
+def head_activate_bwd(y, grad_y, ldz, B=2, C=20, out=None):
+    _chk(y, torch.float32, 'y'); _chk(grad_y, torch.float32, 'grad_y')
+    N, S = y.shape[0], y.shape[1]
+    if out is None:
+        out = torch.empty((N, ldz), dtype=torch.float32, device=y.device)
+    _lib.call('ty1_head_activate_bwd_f32', y.data_ptr(), grad_y.data_ptr(), out.data_ptr(), N, S, B, C, ldz,
+              _lib.current_stream())
+    return out
+
+
+def dense_wgrad(dz, x, units, dwt, db):
+    _chk(dz, torch.float32, 'dz'); _chk(x, torch.float32, 'x'); _chk(dwt, torch.float32, 'dwt'); _chk(db, torch.float32, 'db')
+    N, K = x.shape
+    _lib.call('ty1_dense_wgrad_f32', dz.data_ptr(), x.data_ptr(), dwt.data_ptr(), db.data_ptr(), N, K, units,
+              dwt.shape[1], dz.shape[1], _lib.current_stream())
+    return dwt, db
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
+    for name, a in (('p', p), ('g', g), ('m', m), ('v', v)):
+        _chk(a, torch.float32, name)
+    _lib.call('ty1_adam_step_f32', p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+              float(lr), float(beta1), float(beta2), float(eps), int(t), _lib.current_stream())
+
+
+class KernelTimer:
+    """HIP-event timing of every library launch on its own stream (bench.py roofline leg)."""
+
+    def __enter__(self):
+        _lib.call('ty1_prof_reset')
+        _lib.call('ty1_prof_enable', 1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call('ty1_prof_enable', 0)
+
+    @staticmethod
+    def table():
+        import ctypes
+        buf = ctypes.create_string_buffer(16384)
+        _lib.call('ty1_prof_dump', buf, len(buf))
+        rows = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            rows[name] = (int(n), float(ms))
+        return rows
