@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tiny-YOLOv1 448x448 inference (backbone + Dense + head + decode + NMS).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic images already resident in HBM.
+At N=1 the workload is BASELINE.json configs[1]: batch 64, fp32, one MI355X.  For N>1 every rank
+runs the same per-GPU batch (weak scaling: the path shards by image with no data-path collective)
+and the fixed-size detection records are all-gathered (configs[2]'s "detection gather").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+# libty1 event-timer name -> kernel symbol as rocprofv3 --kernel-trace prints it
+ROCPROF_SYMBOL = {
+    'conv_f32_128x128_pool': 'conv_gemm_f32_kernel<2, 2, 2, 2, 32, 9, true, false>',
+    'conv_f32_128x128': 'conv_gemm_f32_kernel<2, 2, 2, 2, 32, 9, false, false>',
+    'conv_f32_128x64_pool': 'conv_gemm_f32_kernel<2, 1, 2, 2, 32, 9, true, false>',
+    'conv_f32_128x64': 'conv_gemm_f32_kernel<2, 1, 2, 2, 32, 9, false, false>',
+    'conv_f32_64x64_pool': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 9, true, false>',
+    'conv_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 9, false, false>',
+    'conv_f32_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 32, 9, true, false>',
+    'conv_f32_bk16_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 16, 9, true, false>',
+    'conv_f32_bk16_128x64_pool': 'conv_gemm_f32_kernel<2, 1, 2, 2, 16, 9, true, false>',
+    'conv3x3_c3_pool': 'conv3x3_c3_kernel<true>',
+    'dense_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 1, false, true>',
+    'dense_f32_32x128': 'conv_gemm_f32_kernel<1, 1, 1, 4, 32, 1, false, true>',
+    'decode_nms': 'decode_nms_kernel<2>',
+    'head_activate': 'head_activate_kernel',
+}
+
+
+def cpu_baseline(prm, x_cpu, n_images, C=20):
+    """The oracle (CPU restatement of the reference Keras path + NumPy post-processing) timed on the
+    host cores of this box: a reported baseline, not the target."""
+    import oracle
+    from oracle import model_ref
+    threads = torch.get_num_threads()
+    x = x_cpu[:n_images].numpy()
+    bs = 8
+    model_ref.model_ref(x[:2], prm, 7, 2, C)                       # warm-up
+    t0 = time.perf_counter()
+    kept = 0
+    for i in range(0, n_images, bs):
+        y = model_ref.model_ref(x[i:i + bs], prm, 7, 2, C)
+        kept += int(oracle.decode_nms(y, 2, C, 448)['keep'].sum())
+    dt = time.perf_counter() - t0
+    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_images} images of the same synthetic batch in chunks of {bs}: torch-CPU fp32 restatement '
+                      f'of the reference Keras model + C restatement of its NumPy decode/NMS ({dt:.2f} s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
+    ap.add_argument('--cpu-images', type=int, default=32, help='size of the CPU-baseline sample')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from yolo_amd import ops, params as P
+    from yolo_amd.engine import DeviceModel
+
+    N, C = args.batch, 20
+    prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
+    model = DeviceModel(prm, C=C, device=dev)
+    x_cpu = torch.rand((N, 448, 448, 3), generator=torch.Generator(device='cpu').manual_seed(0))
+    x = x_cpu.to(dev)
+    ws = model.workspace(N)
+    gathered = None
+    if world > 1:
+        slots = 98
+        rec = torch.empty((N, slots, 6), dtype=torch.float64, device=dev)          # box(4) score cls*keep
+        gathered = torch.empty((world * N, slots, 6), dtype=torch.float64, device=dev)
+
+    def step():
+        boxes, score, cls, keep = model.detect(x)
+        if world > 1:                                  # detection gather: fixed-size records, one collective
+            rec[..., :4] = boxes
+            rec[..., 4] = score
+            rec[..., 5] = torch.where(keep.bool(), cls, -1)
+            dist.all_gather_into_tensor(gathered, rec)
+        return keep
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    # ---- timed region: exactly K steps; every library launch brackets itself with HIP events on its
+    #      own stream (ops.KernelTimer), which is where the roofline durations come from.
+    with ops.KernelTimer() as kt:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            keep = step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        table = kt.table()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kept_per_image = float(keep.sum().item()) / N
+
+    if rank == 0:
+        # un-instrumented repeat (no event records) to show what the instrumentation costs
+        sync_all() if world == 1 else None
+        plain = None
+        if world == 1:
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize(dev)
+            plain = time.perf_counter() - t1
+        conv = {k: v for k, v in table.items() if k.startswith('conv') and v['ms'] > 0}
+        dom_name = max(conv, key=lambda k: conv[k]['ms'])
+        dom = conv[dom_name]
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        kernels = {}
+        gpu_ms = sum(v['ms'] for v in table.values())
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+            kernels[k] = {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / max(v['launches'], 1), 2),
+                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None,
+                          'algo_gbs': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
+                          'share': round(v['ms'] / gpu_ms, 3)}
+        conv_flops = sum(v['flops'] for k, v in table.items() if k.startswith(('conv', 'dense')))
+        conv_ms = sum(v['ms'] for k, v in table.items() if k.startswith(('conv', 'dense')))
+        out = {
+            'metric': 'images/sec tiny-YOLOv1 448x448 inference incl. decode+NMS',
+            'value': round(world * N * args.steps / elapsed, 1),
+            'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: tiny-YOLOv1 448x448 batch={N}/GPU fp32 backbone+Dense+head+decode+NMS, '
+                                   'random-init weights (glorot, identity BN: dense-candidate NMS stress), '
+                                   'torch.rand images resident in HBM',
+                       'global_batch': world * N, 'per_gpu_batch': N,
+                       'sharding': 'batch split across ranks, no data-path collective'
+                                   + ('; all-gather of fixed-size detection records inside the step' if world > 1 else ''),
+                       'kept_boxes_per_image': round(kept_per_image, 2)},
+            'roofline': {'bound': 'mfma', 'kernel': dom_name, 'rocprof_symbol': ROCPROF_SYMBOL.get(dom_name),
+                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'launches': dom['launches'], 'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
+                         'algo_flops_per_launch': dom['flops'] / dom['launches'],
+                         'all_matmul_kernels_tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                         'whole_step_frac_of_peak': round(
+                             (3.216e9 * world * N * args.steps / elapsed) / (world * PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
+            'kernels': kernels,
+        }
+        if plain is not None:
+            out['uninstrumented_images_per_sec'] = round(N * args.steps / plain, 1)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(prm, x_cpu, min(args.cpu_images, N), C)
+            cb['value'] = round(cb['value'], 2)
+            out['cpu_baseline'] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

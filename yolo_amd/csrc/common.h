@@ -15,10 +15,12 @@ int fail(const char *fmt, ...);
 
 // Event bracket around one kernel launch (only when profiling is enabled on this thread).
 struct ProfScope {
-    ProfScope(const char *name, hipStream_t s);
+    // flops / bytes: ALGORITHMIC work of this launch (for the roofline figure), not measured traffic
+    ProfScope(const char *name, hipStream_t s, double flops = 0.0, double bytes = 0.0);
     ~ProfScope();
     const char *name;
     hipStream_t stream;
+    double flops, bytes;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on;
 };

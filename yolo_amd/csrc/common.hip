@@ -26,12 +26,13 @@ int fail(const char *fmt, ...) {
 struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     int launches = 0;
-    double ms = 0.0;
+    double ms = 0.0, flops = 0.0, bytes = 0.0;
 };
 static thread_local bool g_prof_on = false;
 static thread_local std::map<std::string, ProfEntry> g_prof;
 
-ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), on(g_prof_on) {
+ProfScope::ProfScope(const char *n, hipStream_t s, double fl, double by)
+    : name(n), stream(s), flops(fl), bytes(by), on(g_prof_on) {
     if (!on) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         on = false;
@@ -43,7 +44,10 @@ ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), on(g_pr
 ProfScope::~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, stream);
-    g_prof[name].pending.emplace_back(e0, e1);
+    ProfEntry &e = g_prof[name];
+    e.pending.emplace_back(e0, e1);
+    e.flops += flops;
+    e.bytes += bytes;
 }
 
 static void prof_collect() {
@@ -113,7 +117,8 @@ int ty1_prof_dump(char *buf, size_t cap) {
     size_t off = 0;
     buf[0] = 0;
     for (auto &kv : ty1::g_prof) {
-        int w = snprintf(buf + off, cap - off, "%s %d %.6f\n", kv.first.c_str(), kv.second.launches, kv.second.ms);
+        int w = snprintf(buf + off, cap - off, "%s %d %.6f %.6e %.6e\n", kv.first.c_str(), kv.second.launches,
+                         kv.second.ms, kv.second.flops, kv.second.bytes);
         if (w < 0 || (size_t)w >= cap - off) break;
         off += (size_t)w;
     }

@@ -362,7 +362,11 @@ int launch(const char *name, ConvArgs a, int splits, hipStream_t s) {
     a.mtiles = (int)((a.M + BM - 1) / BM);
     a.ntiles = (a.Cout + BN - 1) / BN;
     dim3 grid(a.mtiles * a.ntiles, splits), block(kThreads);
-    ty1::ProfScope prof(name, s);
+    // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
+    const double K = (double)TAPS * a.Cin;
+    const double out_rows = POOL ? (double)a.M / 4 : (double)a.M;
+    ty1::ProfScope prof(name, s, 2.0 * (double)a.M * a.Cout * K,
+                        4.0 * ((double)a.M * a.Cin + (double)a.Cout * K + out_rows * a.Cout * (RAW ? splits : 1)));
     conv_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, BK, TAPS, POOL, RAW><<<grid, block, 0, s>>>(a);
     return ty1::check_launch(name);
 }
@@ -385,7 +389,9 @@ extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const fl
         const int tiles = ((W + 31) / 32) * ((H + 7) / 8);
         TY1_REQUIRE((long long)N * tiles < (1ll << 31), "ty1_conv3x3: grid too large");
         dim3 grid((unsigned)(N * tiles)), block(kThreads);
-        ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s);
+        const double px = (double)N * H * W;
+        ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s, 2.0 * px * Cout * 27,
+                            4.0 * (px * 3 + 27.0 * Cout + px * Cout / (pool ? 4 : 1)));
         if (pool)
             conv3x3_c3_kernel<true><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha);
         else

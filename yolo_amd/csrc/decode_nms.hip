@@ -217,7 +217,8 @@ extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int
     TY1_REQUIRE(((uintptr_t)boxes & 15) == 0, "ty1_decode_nms: boxes must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((N + 3) / 4), block(256);
-    ty1::ProfScope prof("decode_nms", s);
+    // algorithmic bytes: the head tensor in, (4 f64 + f32 + i32 + u8) per slot out
+    ty1::ProfScope prof("decode_nms", s, 0.0, (double)N * (4.0 * total + 41.0 * S * S * B));
     switch (B) {
         case 1: decode_nms_kernel<1><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
         case 2: decode_nms_kernel<2><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;

@@ -196,6 +196,6 @@ class KernelTimer:
         _lib.call('ty1_prof_dump', buf, len(buf))
         rows = {}
         for line in buf.value.decode().splitlines():
-            name, n, ms = line.split()
-            rows[name] = (int(n), float(ms))
+            name, n, ms, flops, nbytes = line.split()
+            rows[name] = dict(launches=int(n), ms=float(ms), flops=float(flops), bytes=float(nbytes))
         return rows
