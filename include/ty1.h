@@ -93,6 +93,17 @@ int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, 
                    double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream);
 
 /*
+ * NumPy twins used by the reference's inference script (geometry in float64):
+ *   YOLO_head: feats (N,S,S,B,4) f32 -> xy (N,S,S,B,2) f64, wh (N,S,S,B,2) f32
+ *   iou:       n box pairs, mins/maxes (n,2) f64 -> (n) f64
+ * Replace /root/reference/tiny_yolov1.py:36-55 and :58-72 (bit-exact with NumPy).
+ */
+int ty1_yolo_head_np_f64(const float *feats, double *xy, float *wh, int N, int S, int B, int img_size,
+                         ty1_stream_t stream);
+int ty1_iou_f64(const double *pred_mins, const double *pred_maxes, const double *true_mins,
+                const double *true_maxes, double *out, int64_t n, ty1_stream_t stream);
+
+/*
  * box_xy, box_wh = yolo_head(feats, img_size)   (float32 throughout)
  * Replaces /root/reference/yolo/yolo.py:23-45.   feats (N,S,S,B,4) -> xy (N,S,S,B,2), wh (N,S,S,B,2).
  */

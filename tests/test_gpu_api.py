@@ -1,0 +1,183 @@
+"""GPU tests of the drop-in Python entry points (the reference's module paths and names), which
+sit on top of the C-ABI: Model.predict, TinyYOLOv1.detect, yolo_eval / yolo_loss / yolo_head / iou,
+the NumPy twins, and the training step (single process and sharded + summed)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import model_ref, loss_ref
+from conftest import load_golden
+from yolo_amd import ops, params as P, parallel
+from yolo_amd.engine import DeviceModel, Trainer
+from yolo_amd.keras_facade import Model, Adam
+from yolo_amd.models.model_tiny_yolov1 import model_tiny_YOLOv1, ReshapeYOLO
+from yolo_amd.yolo.yolo import yolo_eval, yolo_loss, yolo_head, iou
+from yolo_amd import tiny_yolov1 as ty
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _labels(N, C, seed):
+    rng = np.random.default_rng(seed)
+    y = np.zeros((N, 7, 7, C + 5), np.float32)
+    for n in range(N):
+        for _ in range(3):
+            r, c, k = rng.integers(0, 7), rng.integers(0, 7), rng.integers(0, C)
+            if y[n, r, c, C + 4] == 0:
+                y[n, r, c, k] = 1
+                y[n, r, c, C:C + 4] = rng.random(4)
+                y[n, r, c, C + 4] = 1
+    return y
+
+
+def test_model_predict_and_detect_dropin():
+    outputs, inputs = model_tiny_YOLOv1()
+    model = Model(inputs=inputs, outputs=outputs)
+    prm = P.make_random_params(seed=2, dense_init='spread', bn='random')
+    model.set_params(prm)
+    x = torch.rand((3, 448, 448, 3), generator=torch.Generator().manual_seed(1)).numpy().astype(np.float64)  # load_img dtype
+    y = model.predict(x, batch_size=2)                     # 2 + 1: exercises batching
+    assert isinstance(y, np.ndarray) and y.shape == (3, 7, 7, 30) and y.dtype == np.float32
+    y_ref = model_ref.model_ref(x.astype(np.float32), prm)
+    np.testing.assert_allclose(y, y_ref, rtol=1e-3, atol=1e-4)
+    det = ty.TinyYOLOv1(None, None)
+    det.model.set_params(prm)
+    res = det.detect(x[0].astype(np.float32))
+    want = oracle.decode_nms(y[:1], 2, 20, 448)
+    idx = np.nonzero(want['keep'][0])[0]
+    assert np.array_equal(res[0]['slots'], idx)
+    assert np.array_equal(res[0]['boxes'].view(np.uint64), want['boxes'][0, idx].view(np.uint64))
+    assert res[0]['names'] == [ty.classes_name[c] for c in want['cls'][0, idx]]
+    assert np.array_equal(det.predict(x[0].astype(np.float32)), y[:1])
+
+
+def test_reshape_yolo_call_and_yolo_eval():
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((4, 1470)).astype(np.float32)
+    y = ReshapeYOLO((7, 7, 30)).call(torch.from_numpy(z).to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), model_ref.head_activate_ref(z), rtol=1e-5, atol=1e-6)
+    z1 = rng.standard_normal((4, 539)).astype(np.float32)
+    y1 = ReshapeYOLO((7, 7, 11), C=1).call(torch.from_numpy(z1).to(DEV))
+    np.testing.assert_allclose(y1.cpu().numpy(), model_ref.head_activate_ref(z1, 7, 2, 1), rtol=1e-5, atol=1e-6)
+    g = load_golden('nms_c20.npz')
+    boxes, score, cls, keep = yolo_eval(g['prediction'])
+    want = oracle.decode_nms(g['prediction'])
+    assert np.array_equal(keep.cpu().numpy(), want['keep'])
+    assert np.array_equal(boxes.cpu().numpy().view(np.uint64), want['boxes'].view(np.uint64))
+
+
+def test_numpy_twins_bit_exact():
+    g = load_golden('head_np.npz')
+    xy, wh = ty.YOLO_head(g['feats'])
+    assert xy.dtype == np.float64 and wh.dtype == np.float32
+    assert np.array_equal(xy, g['xy']) and np.array_equal(wh, g['wh'])
+    xy2, wh2 = ty.YOLO_head(g['feats'], img_size=224)
+    assert np.array_equal(xy2, g['xy224']) and np.array_equal(wh2, g['wh224'])
+    got = ty.iou(g['a_min'], g['a_max'], g['b_min'], g['b_max'])
+    assert np.array_equal(got, g['iou'])
+
+
+def test_yolo_loss_autograd_dropin():
+    g = load_golden('loss_c20.npz')
+    yp = torch.from_numpy(g['y_pred']).to(DEV).requires_grad_(True)
+    loss = yolo_loss(torch.from_numpy(g['y_true']).to(DEV), yp)
+    assert loss.dim() == 0
+    (2.0 * loss).backward()
+    assert abs(loss.item() - g['loss']) <= 1e-5 * abs(g['loss'])
+    np.testing.assert_allclose(yp.grad.cpu().numpy(), 2.0 * g['grad'], rtol=1e-4, atol=1e-6)
+    g1 = load_golden('loss_c1.npz')
+    l1 = yolo_loss(g1['y_true'], g1['y_pred'], img_size=224)
+    assert abs(l1.item() - g1['loss']) <= 1e-5 * abs(g1['loss'])
+    xy, wh = yolo_head(g['y_pred'][..., 22:].reshape(-1, 7, 7, 2, 4))
+    assert np.array_equal(xy.cpu().numpy(), g['head_xy'])
+    mins, maxes = xy - wh / 2, xy + wh / 2
+    v = iou(mins[:, :, :, :1], maxes[:, :, :, :1], mins, maxes)          # broadcasting form
+    assert v.shape == (6, 7, 7, 2)
+    np.testing.assert_allclose(v[..., 1].cpu().numpy(), g['iou_b0_b1'], rtol=1e-6)
+
+
+def _torch_train_reference(prm, feats, y_true, steps, C=20):
+    """fp32 torch restatement of the trainable part: Dense -> head -> yolo_loss -> Adam (Keras form)."""
+    w = torch.from_numpy(prm['dense_w'].copy()).requires_grad_(True)
+    b = torch.from_numpy(prm['dense_b'].copy()).requires_grad_(True)
+    m = [torch.zeros_like(w), torch.zeros_like(b)]
+    v = [torch.zeros_like(w), torch.zeros_like(b)]
+    losses = []
+    f, yt = torch.from_numpy(feats), torch.from_numpy(y_true)
+    n = f.shape[0]
+    for t in range(1, steps + 1):
+        z = f @ w + b
+        y = torch.cat([torch.softmax(z[:, :49 * C].reshape(n, 7, 7, C), -1),
+                       torch.sigmoid(z[:, 49 * C:49 * C + 98].reshape(n, 7, 7, 2)),
+                       torch.sigmoid(z[:, 49 * C + 98:].reshape(n, 7, 7, 8))], -1)
+        loss = loss_ref.yolo_loss_ref(yt, y, C)
+        gw, gb = torch.autograd.grad(loss, [w, b])
+        losses.append(loss.item())
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        with torch.no_grad():
+            for p, g, mm, vv in ((w, gw, m[0], v[0]), (b, gb, m[1], v[1])):
+                mm.mul_(0.9).add_(g, alpha=0.1)
+                vv.mul_(0.999).addcmul_(g, g, value=0.001)
+                p.sub_(lr_t * mm / (vv.sqrt() + 1e-7))
+    return losses, w.detach().numpy(), b.detach().numpy()
+
+
+def test_training_step_vs_torch_reference_and_sharded_sum():
+    N = 8
+    prm = P.make_random_params(seed=5, dense_init='spread', bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(3))
+    y_true = _labels(N, 20, 9)
+    model = DeviceModel(prm, device=DEV)
+    xd, yd = x.to(DEV), torch.from_numpy(y_true).to(DEV)
+    feats = model.backbone(xd).cpu().numpy().copy()
+    tr = Trainer(model)
+    # (a) sharded gradients summed (what the RCCL all-reduce does) == full-batch gradients
+    tr.gradients(xd, yd)
+    full_dw, full_db = tr.dwt.clone(), tr.db.clone()
+    la = tr.gradients(xd[:5].contiguous(), yd[:5].contiguous()).clone()
+    dw_a, db_a = tr.dwt.clone(), tr.db.clone()
+    lb = tr.gradients(xd[5:].contiguous(), yd[5:].contiguous()).clone()
+    torch.testing.assert_close(dw_a + tr.dwt, full_dw, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(db_a + tr.db, full_db, rtol=1e-4, atol=1e-6)
+    # (b) three optimizer steps against the torch restatement
+    losses = [tr.step(xd, yd).item() for _ in range(3)]
+    ref_losses, w_ref, b_ref = _torch_train_reference(prm, feats, y_true, 3)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
+    assert abs(la.item() + lb.item() - ref_losses[0]) <= 2e-4 * ref_losses[0]
+    w_got = P.dense_from_device_layout(model.dense_wt.cpu().numpy(), model.units)
+    np.testing.assert_allclose(w_got, w_ref, rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(model.dense_b.cpu().numpy(), b_ref, rtol=1e-3, atol=2e-5)
+    assert losses[2] < losses[0]                                     # it learns
+
+
+def test_keras_style_training_entry_points(tmp_path):
+    outputs, inputs = model_tiny_YOLOv1()
+    model = Model(inputs=inputs, outputs=outputs)
+    model.compile(loss=yolo_loss, optimizer=Adam(lr=0.001))
+    x = torch.rand((4, 448, 448, 3), generator=torch.Generator().manual_seed(4)).numpy()
+    y = _labels(4, 20, 1)
+
+    class Gen:
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return x, y
+
+    hist = model.fit_generator(Gen(), steps_per_epoch=2, epochs=2, validation_data=Gen(), validation_steps=1, verbose=0)
+    assert hist['loss'][1] < hist['loss'][0] and len(hist['val_loss']) == 2
+    model.save_weights(str(tmp_path / 'trained.npz'))
+    m2 = Model(inputs=inputs, outputs=outputs, seed=99)
+    m2.load_weights(str(tmp_path / 'trained.npz'))
+    np.testing.assert_array_equal(m2.predict(x[:1]), model.predict(x[:1]))
+
+
+def test_detection_records_roundtrip_on_device():
+    g = load_golden('nms_c20.npz')
+    det = ops.decode_nms(torch.from_numpy(g['prediction']).to(DEV))
+    rec = parallel.pack_detections(*det)
+    boxes, score, cls, keep = parallel.unpack_detections(parallel.gather_detections(rec))
+    assert torch.equal(boxes, det[0]) and torch.equal(keep, det[3]) and torch.equal(score, det[1])
+    assert torch.equal(cls[keep.bool()], det[2][keep.bool()])

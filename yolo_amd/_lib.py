@@ -16,6 +16,8 @@ SIGNATURES = {
     'ty1_dense_splitk_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_head_activate_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_decode_nms': [_vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
+    'ty1_yolo_head_np_f64': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'ty1_iou_f64': [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'ty1_yolo_head_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'ty1_iou_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'ty1_yolo_loss_fwd_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

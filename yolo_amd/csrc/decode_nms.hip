@@ -200,7 +200,54 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict
     }
 }
 
+// NumPy twins of the reference (tiny_yolov1.py:36-72): YOLO_head with xy in float64 and wh in float32,
+// iou in float64.  feats has no batch axis there; a leading batch axis is accepted here.
+__global__ void yolo_head_np_kernel(const float *__restrict__ feats, double *__restrict__ xy, float *__restrict__ wh,
+                                    long long nbox, int S, int B, int img_size) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbox) return;
+    const long long cell = i / B;
+    const int c = (int)(cell % S), r = (int)((cell / S) % S);
+    const float4 f = reinterpret_cast<const float4 *>(feats)[i];
+    xy[2 * i + 0] = ((double)f.x + (double)c) / (double)S * (double)img_size;
+    xy[2 * i + 1] = ((double)f.y + (double)r) / (double)S * (double)img_size;
+    wh[2 * i + 0] = f.z * (float)img_size;
+    wh[2 * i + 1] = f.w * (float)img_size;
+}
+
+__global__ void iou_f64_kernel(const double *__restrict__ pmin, const double *__restrict__ pmax,
+                               const double *__restrict__ tmin, const double *__restrict__ tmax,
+                               double *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = iou_f64(pmin + 2 * i, pmax + 2 * i, tmin + 2 * i, tmax + 2 * i);
+}
+
 }  // namespace
+
+extern "C" int ty1_yolo_head_np_f64(const float *feats, double *xy, float *wh, int N, int S, int B, int img_size,
+                                    ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && B > 0 && img_size > 0, "ty1_yolo_head_np: bad dimensions");
+    const long long nbox = (long long)N * S * S * B;
+    if (nbox == 0) return 0;
+    TY1_REQUIRE(feats && xy && wh, "ty1_yolo_head_np: null pointer");
+    TY1_REQUIRE(((uintptr_t)feats & 15) == 0, "ty1_yolo_head_np: feats must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ty1::ProfScope prof("yolo_head_np", s);
+    yolo_head_np_kernel<<<dim3((unsigned)((nbox + 255) / 256)), dim3(256), 0, s>>>(feats, xy, wh, nbox, S, B, img_size);
+    return ty1::check_launch("ty1_yolo_head_np_f64");
+}
+
+extern "C" int ty1_iou_f64(const double *pred_mins, const double *pred_maxes, const double *true_mins,
+                           const double *true_maxes, double *out, int64_t n, ty1_stream_t stream) {
+    TY1_REQUIRE(n >= 0, "ty1_iou_f64: negative count");
+    if (n == 0) return 0;
+    TY1_REQUIRE(pred_mins && pred_maxes && true_mins && true_maxes && out, "ty1_iou_f64: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ty1::ProfScope prof("iou_f64", s);
+    iou_f64_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(pred_mins, pred_maxes, true_mins, true_maxes, out, n);
+    return ty1::check_launch("ty1_iou_f64");
+}
 
 extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, double iou_thr,
                               double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream) {

@@ -12,18 +12,20 @@ from .params import CONV_CHANNELS, N_POOL, BN_EPS, LEAKY_ALPHA, hwio_to_ohwi, de
 
 
 class DeviceModel:
-    def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0'):
+    def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0', conv_specs=None):
         self.S, self.B, self.C, self.img_size = S, B, C, img_size
         self.device = torch.device(device)
         self.units = S * S * (C + 5 * B)
+        # (cin, cout, pool) per conv block; default = cfg/yolov1-tiny.cfg as transcribed by the reference
+        self.specs = conv_specs or [(ci, co, i < N_POOL) for i, (ci, co) in enumerate(CONV_CHANNELS)]
         self.conv = []
-        for i, (cin, cout) in enumerate(CONV_CHANNELS):
+        for i, (cin, cout, pool) in enumerate(self.specs):
             scale, shift = ops.fold_bn(params[f'bn{i}_gamma'], params[f'bn{i}_beta'], params[f'bn{i}_mean'],
                                        params[f'bn{i}_var'], BN_EPS)
             self.conv.append(dict(
                 w=torch.from_numpy(hwio_to_ohwi(params[f'conv{i}_w'])).to(self.device),
                 scale=torch.from_numpy(scale).to(self.device), shift=torch.from_numpy(shift).to(self.device),
-                pool=i < N_POOL))
+                pool=pool))
         assert params['dense_w'].shape[1] == self.units, (params['dense_w'].shape, self.units)
         self.dense_wt = torch.from_numpy(dense_to_device_layout(params['dense_w'])).to(self.device)
         self.dense_b = torch.from_numpy(np.ascontiguousarray(params['dense_b'], np.float32)).to(self.device)
@@ -36,8 +38,8 @@ class DeviceModel:
         if ws is None:
             dev, f32 = self.device, torch.float32
             acts, h = [], self.img_size
-            for i, (_, cout) in enumerate(CONV_CHANNELS):
-                if i < N_POOL:
+            for _, cout, pool in self.specs:
+                if pool:
                     h //= 2
                 acts.append(torch.empty((N, h, h, cout), dtype=f32, device=dev))
             splits = ops.pick_splits(self.K, N, self.units)
@@ -75,3 +77,50 @@ class DeviceModel:
         ws = self.workspace(x.shape[0])
         y = self.head(self.backbone(x, ws), ws)
         return ops.decode_nms(y, self.B, self.C, self.img_size, iou_thr, out=ws['det'])
+
+
+class Trainer:
+    """One training step of the reference's configuration (train.py:59-60): the frozen
+    backbone and the Dense layer run forward, yolo_loss gives dL/dy_pred in closed form, the head
+    Jacobian and the Dense weight gradient follow, gradients are all-reduced with SUM over the
+    data-parallel group (the loss is a batch sum: SURVEY Q12, no division by world size), and Adam
+    (Keras defaults) updates the only trainable parameters: the Dense kernel and bias (Q8)."""
+
+    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None):
+        self.model, self.group = model, group
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        dev = model.device
+        self.dwt = torch.zeros_like(model.dense_wt)
+        self.db = torch.zeros_like(model.dense_b)
+        self.m_w, self.v_w = torch.zeros_like(model.dense_wt), torch.zeros_like(model.dense_wt)
+        self.m_b, self.v_b = torch.zeros_like(model.dense_b), torch.zeros_like(model.dense_b)
+        self.t = 0
+        self.ldz = ops.round_up(model.units, 4)
+        self._dz = {}
+        self.device = dev
+
+    def gradients(self, x, y_true):
+        """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
+        m = self.model
+        N = x.shape[0]
+        ws = m.workspace(N)
+        feats = m.backbone(x, ws)
+        y = m.head(feats, ws)
+        loss, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size)
+        dz = self._dz.get(N)
+        if dz is None:
+            dz = self._dz[N] = torch.empty((N, self.ldz), dtype=torch.float32, device=self.device)
+        ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
+        ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
+        return loss
+
+    def step(self, x, y_true):
+        """x (n,448,448,3), y_true (n,S,S,C+5) on the device -> global batch loss (1,) on the device."""
+        from . import parallel
+        loss = self.gradients(x, y_true)
+        parallel.allreduce_sum_([self.dwt, self.db, loss], self.group)
+        self.t += 1
+        m = self.model
+        ops.adam_step(m.dense_wt, self.dwt, self.m_w, self.v_w, self.t, self.lr, self.beta1, self.beta2, self.eps)
+        ops.adam_step(m.dense_b, self.db, self.m_b, self.v_b, self.t, self.lr, self.beta1, self.beta2, self.eps)
+        return loss

@@ -138,6 +138,30 @@ def iou(pred_mins, pred_maxes, true_mins, true_maxes):
     return out
 
 
+def yolo_head_np(feats, img_size=448):
+    """NumPy twin: feats (...,S,S,B,4) f32 -> xy float64, wh float32 (tiny_yolov1.py:36-55)."""
+    _chk(feats, torch.float32, 'feats')
+    shape = feats.shape
+    S, B = shape[-3], shape[-2]
+    if shape[-1] != 4 or shape[-4] != S:
+        raise ValueError(f'feats must be (...,S,S,B,4), got {tuple(shape)}')
+    N = feats.numel() // (S * S * B * 4)
+    xy = torch.empty(shape[:-1] + (2,), dtype=torch.float64, device=feats.device)
+    wh = torch.empty(shape[:-1] + (2,), dtype=torch.float32, device=feats.device)
+    _lib.call('ty1_yolo_head_np_f64', feats.data_ptr(), xy.data_ptr(), wh.data_ptr(), N, S, B, int(img_size),
+              _lib.current_stream())
+    return xy, wh
+
+
+def iou_f64(pred_mins, pred_maxes, true_mins, true_maxes):
+    shape = torch.broadcast_shapes(pred_mins.shape, pred_maxes.shape, true_mins.shape, true_maxes.shape)
+    ops_ = [_chk(t.to(torch.float64).expand(shape).contiguous(), torch.float64, 'iou operand')
+            for t in (pred_mins, pred_maxes, true_mins, true_maxes)]
+    out = torch.empty(shape[:-1], dtype=torch.float64, device=ops_[0].device)
+    _lib.call('ty1_iou_f64', *(o.data_ptr() for o in ops_), out.data_ptr(), out.numel(), _lib.current_stream())
+    return out
+
+
 def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True):
     """-> loss (1,) f32 batch SUM, loss_per_image (N,), grad (N,S,S,C+5B) or None."""
     _chk(y_true, torch.float32, 'y_true'); _chk(y_pred, torch.float32, 'y_pred')

@@ -1,0 +1,64 @@
+"""Data-parallel helpers: one process per GPU, torch.distributed ('nccl' == RCCL over xGMI on ROCm;
+'gloo' in the CPU tests).  The hot path shards by image, so inference needs no data-path
+collective; the only exchanges are (a) the SUM all-reduce of the Dense gradient in training and
+(b) an optional all-gather of fixed-size detection records.  These helpers are
+device-agnostic on purpose: the same code runs under gloo with CPU tensors in tests/."""
+import torch
+import torch.distributed as dist
+
+
+def world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous, near-even split of n images: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allreduce_sum_(tensors, group=None):
+    """In-place SUM all-reduce (no averaging: yolo_loss is a batch sum)."""
+    if world(group)[1] == 1:
+        return tensors
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return tensors
+
+
+RECORD_WIDTH = 6        # x0, y0, x1, y1, score, class (-1 where the slot is not kept)
+
+
+def pack_detections(boxes, score, cls, keep):
+    """-> (n, slots, 6) float64 fixed-size records (float64 keeps the box corners bit-exact)."""
+    rec = torch.empty(boxes.shape[:2] + (RECORD_WIDTH,), dtype=torch.float64, device=boxes.device)
+    rec[..., :4] = boxes
+    rec[..., 4] = score
+    rec[..., 5] = torch.where(keep.bool(), cls, torch.full_like(cls, -1))
+    return rec
+
+
+def unpack_detections(rec):
+    keep = rec[..., 5] >= 0
+    return rec[..., :4], rec[..., 4].float(), rec[..., 5].clamp(min=0).int(), keep.to(torch.uint8)
+
+
+def gather_detections(rec, counts=None, group=None):
+    """All-gather per-rank records into the global batch order.  `counts` = per-rank image counts
+    (needed only when shards are ragged; equal shards use one all_gather_into_tensor)."""
+    rank, ws = world(group)
+    if ws == 1:
+        return rec
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty((ws * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+        return out
+    cap = max(counts)
+    padded = torch.zeros((cap,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    padded[:rec.shape[0]] = rec
+    out = torch.empty((ws * cap,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * cap:r * cap + counts[r]] for r in range(ws)], dim=0)
