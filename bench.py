@@ -36,7 +36,7 @@ ROCPROF_SYMBOL = {
     'conv_f32_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 32, 9, true, false>',
     'conv_f32_bk16_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 16, 9, true, false>',
     'conv_f32_bk16_128x64_pool': 'conv_gemm_f32_kernel<2, 1, 2, 2, 16, 9, true, false>',
-    'conv3x3_c3_pool': 'conv3x3_c3_kernel<true>',
+    'conv3x3_c3_pool': 'conv3x3_c3_kernel<true, 1>',
     'dense_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 1, false, true>',
     'dense_f32_32x128': 'conv_gemm_f32_kernel<1, 1, 1, 4, 32, 1, false, true>',
     'decode_nms': 'decode_nms_kernel<2>',
@@ -146,7 +146,14 @@ def main():
                 step()
             torch.cuda.synchronize(dev)
             plain = time.perf_counter() - t1
-        conv = {k: v for k, v in table.items() if k.startswith('conv') and v['ms'] > 0}
+        # per-layer entries are named "<kernel>@<H>x<Cin>><Cout>"; the roofline object is quoted per kernel
+        # symbol (what rocprofv3 --stats aggregates), so fold the layers of one instantiation together
+        conv = {}
+        for k, v in table.items():
+            if k.startswith('conv') and v['ms'] > 0:
+                e = conv.setdefault(k.split('@')[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                for f in e:
+                    e[f] += v[f]
         dom_name = max(conv, key=lambda k: conv[k]['ms'])
         dom = conv[dom_name]
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12

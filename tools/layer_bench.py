@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Developer tool: time every conv layer of the model alone (batch N) and print TFLOP/s per layer."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from yolo_amd import ops, params as P  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=64)
+ap.add_argument('--iters', type=int, default=20)
+ap.add_argument('--layers', default='0,1,2,3,4,5,6,7')
+args = ap.parse_args()
+dev = 'cuda:0'
+h = 448
+tot = 0.0
+for i, (cin, cout) in enumerate(P.CONV_CHANNELS):
+    pool = i < P.N_POOL
+    if str(i) in args.layers.split(','):
+        x = torch.rand((args.batch, h, h, cin), device=dev)
+        w = torch.randn((cout, 3, 3, cin), device=dev) * 0.05
+        sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        out = ops.conv3x3_bn_leaky(x, w, sc, sh, pool)
+        for _ in range(3):
+            ops.conv3x3_bn_leaky(x, w, sc, sh, pool, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.conv3x3_bn_leaky(x, w, sc, sh, pool, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        fl = 2.0 * args.batch * h * h * 9 * cin * cout
+        tot += us
+        print(f'L{i} {h}x{h} {cin}->{cout} pool={int(pool)}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s', flush=True)
+    if pool:
+        h //= 2
+print(f'total {tot:.1f} us -> {args.batch / tot * 1e6:.0f} img/s (conv only)')

@@ -18,7 +18,7 @@ struct ProfScope {
     // flops / bytes: ALGORITHMIC work of this launch (for the roofline figure), not measured traffic
     ProfScope(const char *name, hipStream_t s, double flops = 0.0, double bytes = 0.0);
     ~ProfScope();
-    const char *name;
+    std::string name;
     hipStream_t stream;
     double flops, bytes;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -258,23 +258,27 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// First layer (Cin = 3, K = 27): the input halo tile is staged once in LDS with fully coalesced row
-// loads (NHWC with C=3: a tile row is 3*(TW+2) contiguous floats) and all 27 k values of a pixel
-// are read from it; weights (Cout x 28, zero padded) live in LDS too.  MFMA 16x16x4 when Cout==16.
-// Tile: TH x TW = 8 x 32 output pixels (pre-pool) per block, 4 waves, each wave 2 rows x 32 px.
+// First layer (Cin = 3, K = 27 -> 28): direct convolution on v_mfma_f32_16x16x4_f32.
+// A block owns a 16 x 64 pixel tile (pre-pool).  Its 18 x 66 x 3 input halo tile is staged ONCE in LDS
+// with coalesced row loads (NHWC, C=3: a tile row is 198 contiguous floats) and all 27 taps of a pixel
+// are read from it: for a fixed kh the 9 (kw,ci) values of a pixel are contiguous in LDS.  Each lane
+// keeps its 7 weight values per 16-channel group in registers for the whole tile.  Each wave owns
+// 4 rows x 64 px = 16 M-tiles of 16 pixels (= 4 pool windows x 4), two M-tiles in flight so the
+// dependent-accumulator latency (40 cycles) hides behind the 32-cycle issue of the other chain.
+// Operand maps (16x16x4): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
+// C/D: col = lane&15 (channel), row = 4*(lane>>4) + reg  ->  one lane holds one whole pool window.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool POOL>
+template <bool POOL, int NT>
 __global__ __launch_bounds__(kThreads) void conv3x3_c3_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, float *__restrict__ y,
                                                               int NB, int H, int W, int Cout, float alpha) {
-    constexpr int TH = 8, TW = 32, CIN = 3;
-    constexpr int ROW = 112;                // floats per LDS tile row: >= 3*(TW+2)=102, ROW % 32 == 16
-    constexpr int KPAD = 29;             // 28 k values (27 + zero pad), odd stride: conflict-free B reads
+    constexpr int TH = 16, TW = 64;
+    constexpr int ROWF = 3 * (TW + 2);      // 198 floats of input per tile row
+    constexpr int ROW = 208;                // LDS row stride; 208 % 32 == 16 spreads the two pixel rows of a window
     __shared__ float tile[(TH + 2) * ROW];
-    __shared__ float wl[64 * KPAD];         // up to 64 output channels
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -284,16 +288,30 @@ __global__ __launch_bounds__(kThreads) void conv3x3_c3_kernel(const float *__res
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
+    const int i16 = lane & 15, kq = lane >> 4;
 
-    // stage weights: wl[co][k'] with k' = kh*9 + kw*3 + ci  (== OHWI order), zero pad to 28
-    for (int i = tid; i < Cout * KPAD; i += kThreads) {
-        const int co = i / KPAD, k = i - co * KPAD;
-        wl[i] = k < 27 ? w[co * 27 + k] : 0.f;            // k = 27, 28: zero pad
+    // weights of this lane: B[k = 4*ks + kq][channel 16*j + i16]; k = 27 is the zero pad
+    float wreg[NT][7];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int k = 4 * ks + kq;
+            wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] : 0.f;
+        }
+    // A-operand LDS offset of this lane for every k step, relative to the pixel's top-left tap
+    int koff[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int k = 4 * ks + kq;
+        const int kh = k / 9;
+        koff[ks] = k < 27 ? kh * ROW + (k - 9 * kh) : 0;     // k = 27: any valid address (weight is 0)
     }
-    // stage the input halo tile: rows y0-1 .. y0+TH, columns x0-1 .. x0+TW  (zero outside)
-    const float *img = x + (long long)n * H * W * CIN;
-    for (int i = tid; i < (TH + 2) * 3 * (TW + 2); i += kThreads) {
-        const int rr = i / (3 * (TW + 2)), cc = i - rr * (3 * (TW + 2));
+
+    // stage the halo tile: rows y0-1 .. y0+TH, float columns 3*(x0-1) .. 3*(x0+TW+1)-1, zero outside
+    const float *img = x + (long long)n * H * W * 3;
+    for (int i = tid; i < (TH + 2) * ROWF; i += kThreads) {
+        const int rr = i / ROWF, cc = i - rr * ROWF;
         const int yy = y0 - 1 + rr, xx3 = (x0 - 1) * 3 + cc;
         float v = 0.f;
         if (yy >= 0 && yy < H && xx3 >= 0 && xx3 < W * 3) v = img[(long long)yy * W * 3 + xx3];
@@ -301,58 +319,78 @@ __global__ __launch_bounds__(kThreads) void conv3x3_c3_kernel(const float *__res
     }
     __syncthreads();
 
-    // Each wave: rows 2*wave, 2*wave+1 of the tile, 32 px wide = 64 pixels = 4 M-tiles of 16.
-    // M-tile t (0..3) covers pool windows 4t..4t+3 of the 16 windows in this 2x32 strip:
-    //   m = 4*wl_ + q  ->  window wl_ = 4t + (m>>2), px = 2*window + (q&1), py = q>>1.
-    // 16x16x4 operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15];
-    // C/D: col = lane&15, row = 4*(lane>>4) + reg.
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int ntile = Cout / 16;
-    for (int t = 0; t < 4; ++t) {
-        const int window = 4 * t + (i16 >> 2), q = i16 & 3;
-        const int px = 2 * window + (q & 1), py = 2 * wave + (q >> 1);
-        f32x4 acc[4];
+    float sc[NT], sh[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) {
+        sc[j] = scale[16 * j + i16];
+        sh[j] = shift[16 * j + i16];
+    }
+    // pixel of this lane inside an M-tile: window (i16>>2) of 4, position q = i16&3 in the 2x2 window
+    const int q = i16 & 3;
+    const int lane_px = 2 * (i16 >> 2) + (q & 1), lane_py = q >> 1;
+
+    for (int t2 = 0; t2 < 16; t2 += 2) {               // two M-tiles per iteration (independent chains)
+        f32x4 acc[2][NT];
+        int base[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = t2 + u;
+            const int pr = t >> 3, wcol = (t & 7) * 4;           // pooled row in the wave's strip, first window
+            const int py = 4 * wave + 2 * pr + lane_py, px = 2 * wcol + lane_px;
+            base[u] = py * ROW + px * 3;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < 7; ++ks) {
-            const int k = 4 * ks + kq;                       // 0..27 (27 = zero pad)
-            const int kh = k / 9, rem = k - kh * 9;           // k=27 -> kh=3, rem=0: weight is 0
-            const float av = k < 27 ? tile[(py + kh) * ROW + px * 3 + rem] : 0.f;
+            const float a0 = tile[base[0] + koff[ks]];
+            const float a1 = tile[base[1] + koff[ks]];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < ntile) {
-                    const float bv = wl[(16 * j + i16) * KPAD + k];
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
-                }
+            for (int j = 0; j < NT; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[j][ks], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[j][ks], acc[1][j], 0, 0, 0);
             }
         }
-        // epilogue: lane holds channel 16j + i16 for tile rows 4*kq + reg = one pool window (kq)
+        // epilogue: this lane holds pool window (wcol + kq) of pooled row pr, channel 16j + i16
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j >= ntile) continue;
-            const int co = 16 * j + i16;
-            const float sc = scale[co], sh = shift[co];
-            float v[4];
+        for (int u = 0; u < 2; ++u) {
+            const int t = t2 + u;
+            const int pr = t >> 3, win = (t & 7) * 4 + kq;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = acc[j][r] * sc + sh;
-                v[r] = u > 0.f ? u : u * alpha;
-            }
-            const int win = 4 * t + kq;                       // window index in the strip (0..15)
-            if (POOL) {
-                const int oy = (y0 >> 1) + wave, ox = (x0 >> 1) + win;
-                if (oy < (H >> 1) && ox < (W >> 1))
-                    y[(((long long)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] =
-                        fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            } else {
+            for (int j = 0; j < NT; ++j) {
+                const int co = 16 * j + i16;
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int oy = y0 + 2 * wave + (r >> 1), ox = x0 + 2 * win + (r & 1);
-                    if (oy < H && ox < W) y[(((long long)n * H + oy) * W + ox) * Cout + co] = v[r];
+                    const float z = acc[u][j][r] * sc[j] + sh[j];
+                    v[r] = z > 0.f ? z : z * alpha;
+                }
+                if (POOL) {
+                    const int oy = (y0 >> 1) + 2 * wave + pr, ox = (x0 >> 1) + win;
+                    if (oy < (H >> 1) && ox < (W >> 1))
+                        y[(((long long)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] =
+                            fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oy = y0 + 4 * wave + 2 * pr + (r >> 1), ox = x0 + 2 * win + (r & 1);
+                        if (oy < H && ox < W) y[(((long long)n * H + oy) * W + ox) * Cout + co] = v[r];
+                    }
                 }
             }
         }
+    }
+}
+
+template <bool POOL>
+void launch_c3(int nt, dim3 grid, hipStream_t s, const float *x, const float *w, const float *scale, const float *shift,
+               float *y, int N, int H, int W, int Cout, float alpha) {
+    dim3 block(kThreads);
+    switch (nt) {
+        case 1: conv3x3_c3_kernel<POOL, 1><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha); break;
+        case 2: conv3x3_c3_kernel<POOL, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha); break;
+        case 3: conv3x3_c3_kernel<POOL, 3><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha); break;
+        default: conv3x3_c3_kernel<POOL, 4><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha); break;
     }
 }
 
@@ -365,7 +403,9 @@ int launch(const char *name, ConvArgs a, int splits, hipStream_t s) {
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
     const double K = (double)TAPS * a.Cin;
     const double out_rows = POOL ? (double)a.M / 4 : (double)a.M;
-    ty1::ProfScope prof(name, s, 2.0 * (double)a.M * a.Cout * K,
+    char tag[96];
+    snprintf(tag, sizeof tag, "%s@%dx%d>%d", name, a.H, a.Cin, a.Cout);
+    ty1::ProfScope prof(tag, s, 2.0 * (double)a.M * a.Cout * K,
                         4.0 * ((double)a.M * a.Cin + (double)a.Cout * K + out_rows * a.Cout * (RAW ? splits : 1)));
     conv_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, BK, TAPS, POOL, RAW><<<grid, block, 0, s>>>(a);
     return ty1::check_launch(name);
@@ -386,16 +426,16 @@ extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const fl
 
     if (Cin == 3) {
         TY1_REQUIRE(Cout <= 64, "ty1_conv3x3: Cin=3 path supports Cout <= 64 (got %d)", Cout);
-        const int tiles = ((W + 31) / 32) * ((H + 7) / 8);
+        const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
         TY1_REQUIRE((long long)N * tiles < (1ll << 31), "ty1_conv3x3: grid too large");
-        dim3 grid((unsigned)(N * tiles)), block(kThreads);
+        dim3 grid((unsigned)(N * tiles));
         const double px = (double)N * H * W;
         ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s, 2.0 * px * Cout * 27,
                             4.0 * (px * 3 + 27.0 * Cout + px * Cout / (pool ? 4 : 1)));
         if (pool)
-            conv3x3_c3_kernel<true><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha);
+            launch_c3<true>(Cout / 16, grid, s, x, w, scale, shift, y, N, H, W, Cout, alpha);
         else
-            conv3x3_c3_kernel<false><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha);
+            launch_c3<false>(Cout / 16, grid, s, x, w, scale, shift, y, N, H, W, Cout, alpha);
         return ty1::check_launch("ty1_conv3x3(c3)");
     }
 
