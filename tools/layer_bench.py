@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--layers', default='0,1,2,3,4,5,6,7')
+ap.add_argument('--shapes', default='', help='extra cases "N,H,cin,cout,pool;..."')
 args = ap.parse_args()
 dev = 'cuda:0'
 h = 448
@@ -38,4 +39,21 @@ for i, (cin, cout) in enumerate(P.CONV_CHANNELS):
         print(f'L{i} {h}x{h} {cin}->{cout} pool={int(pool)}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s', flush=True)
     if pool:
         h //= 2
+for spec in [t for t in args.shapes.split(';') if t]:
+    n, hh, cin, cout, pool = (int(v) for v in spec.split(','))
+    x = torch.rand((n, hh, hh, cin), device=dev)
+    w = torch.randn((cout, 3, 3, cin), device=dev) * 0.05
+    sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    out = ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool))
+    for _ in range(3):
+        ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.iters
+    fl = 2.0 * n * hh * hh * 9 * cin * cout
+    print(f'shape {spec}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s', flush=True)
 print(f'total {tot:.1f} us -> {args.batch / tot * 1e6:.0f} img/s (conv only)')

@@ -17,6 +17,9 @@
 // the ds_read_b128 16-lane groups), next chunk prefetched into registers during the MFMAs.
 #include "common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,12 +51,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, bool RAW>
-__global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs a) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(const ConvArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per block");
+    constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int LDS_STRIDE = BK + 4;
     constexpr int CPR = BK / 4;               // 16-byte pieces per tile row
-    constexpr int RPP = kThreads / CPR;       // tile rows covered per pass
+    constexpr int RPP = NTHREADS / CPR;       // tile rows covered per pass
     constexpr int AP = (BM + RPP - 1) / RPP;  // passes for the A tile
     constexpr int BP = (BN + RPP - 1) / RPP;  // passes for the B tile
 
@@ -63,6 +67,12 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
+    // Two blocks share a CU, i.e. two waves share each SIMD's matrix pipe.  Running the same program at
+    // equal priority they fall into lockstep and stall together at every barrier / LDS-store phase.
+    // Give the wave in the odd hardware wave slot a higher static priority: it issues whenever it can,
+    // the partner fills its gaps, and the two drift apart.  (HW_REG_HW_ID[3:0] = wave slot on the SIMD.)
+    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(1);
+
     const int nwg = a.mtiles * a.ntiles;
     const int logical = xcd_remap(blockIdx.x, nwg);
     const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
@@ -70,37 +80,58 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
 
     const int piece = tid % CPR, prow = tid / CPR;
 
-    // ---- per-thread A row descriptors (fixed for the whole K loop)
-    long long a_base[AP];
-    unsigned a_mask[AP];
+    // ---- operands are fetched with raw buffer loads: an out-of-range offset returns 0, which gives the
+    //      zero padding of the 3x3 halo, the M / N tails and a branch-free K loop (one basic block that
+    //      the scheduler can interleave with the MFMAs).  Offsets are 32-bit bytes relative to the first
+    //      image this block touches, so tensors larger than 4 GiB still work.
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
+    const long long m_first = (long long)mt * BM;
+    long long a_origin;                       // element offset of the block's buffer base inside x
+    if (TAPS == 1) {
+        a_origin = m_first * a.Cin;
+    } else {
+        const long long pix = POOL ? (m_first >> 2) / ((a.H >> 1) * (a.W >> 1)) : m_first / ((long long)a.H * a.W);
+        a_origin = pix * a.H * a.W * a.Cin;
+    }
+    const long long a_total = (TAPS == 1 ? a.M : (long long)a.NB * a.H * a.W) * a.Cin;
+    const long long a_left = (a_total - a_origin) * 4;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x + a_origin), 0, (int)(a_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_left), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, (int)((long long)a.Cout * a.ldw * 4), 0x00020000);
+
+    unsigned a_base[AP];                      // byte offset of the row's centre pixel (or row start)
+    unsigned a_mask[AP];                      // bit t: tap t lies inside the image
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         const int row = p * RPP + prow;
-        const long long m = (long long)mt * BM + row;
+        const long long m = m_first + row;
         a_base[p] = 0;
         a_mask[p] = 0;
         if (row < BM && m < a.M) {
             if (TAPS == 1) {
-                a_base[p] = m * a.Cin;
+                a_base[p] = (unsigned)((long long)row * a.Cin * 4);
                 a_mask[p] = 1;
             } else {
-                int n, yy, xx;
+                long long n;
+                int yy, xx;
                 if (POOL) {
                     const int Hp = a.H >> 1, Wp = a.W >> 1;
                     const long long win = m >> 2;
                     const int q = (int)(m & 3);
-                    n = (int)(win / (Hp * Wp));
-                    const int rem = (int)(win - (long long)n * (Hp * Wp));
+                    n = win / (Hp * Wp);
+                    const int rem = (int)(win - n * (Hp * Wp));
                     const int py = rem / Wp, px = rem - py * Wp;
                     yy = 2 * py + (q >> 1);
                     xx = 2 * px + (q & 1);
                 } else {
-                    n = (int)(m / (a.H * a.W));
-                    const int rem = (int)(m - (long long)n * (a.H * a.W));
+                    n = m / (a.H * a.W);
+                    const int rem = (int)(m - n * (a.H * a.W));
                     yy = rem / a.W;
                     xx = rem - yy * a.W;
                 }
-                a_base[p] = (((long long)n * a.H + yy) * a.W + xx) * a.Cin;
+                const long long el = ((n * a.H + yy) * a.W + xx) * a.Cin - a_origin;
+                a_base[p] = (unsigned)(el * 4);
                 unsigned mask = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -111,22 +142,20 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
             }
         }
     }
-    // ---- per-thread B row descriptors
-    long long b_base[BP];
-    bool b_ok[BP];
+    unsigned b_base[BP];
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
         const int row = p * RPP + prow;
         const int n = nt * BN + row;
-        b_ok[p] = row < BN && n < a.Cout;
-        b_base[p] = (long long)n * a.ldw;
+        b_base[p] = (row < BN && n < a.Cout) ? (unsigned)((long long)n * a.ldw * 4) : kOOB;
     }
 
     const int chunks_per_tap = a.Cin / BK;
     const int kc_begin = split * a.chunks_per_split;
     const int kc_end = kc_begin + a.chunks_per_split;
 
-    float4 ra[AP], rb[BP];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[AP], rb[BP];
     auto load_chunk = [&](int kc) {
         int tap, ci0;
         if (TAPS == 1) {
@@ -137,33 +166,29 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
             ci0 = (kc - tap * chunks_per_tap) * BK;
         }
         const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap % 3 - 1;
-        const long long delta = (long long)(dy * a.W + dx) * a.Cin + ci0 + piece * 4;
+        const int delta = (((dy * a.W + dx) * a.Cin) + ci0 + piece * 4) * 4;      // bytes, may be negative
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            if ((a_mask[p] >> tap) & 1u)
-                ra[p] = *reinterpret_cast<const float4 *>(a.x + a_base[p] + delta);
-            else
-                ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = ((a_mask[p] >> tap) & 1u) ? a_base[p] + (unsigned)delta : kOOB;
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
         }
-        const long long koff = (long long)kc * BK + piece * 4;
+        const unsigned koff = (unsigned)(kc * BK + piece * 4) * 4u;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
-            if (b_ok[p])
-                rb[p] = *reinterpret_cast<const float4 *>(a.w + b_base[p] + koff);
-            else
-                rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = b_base[p] == kOOB ? kOOB : b_base[p] + koff;
+            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const int row = p * RPP + prow;
-            if (row < BM) *reinterpret_cast<float4 *>(&As[buf][row * LDS_STRIDE + piece * 4]) = ra[p];
+            if (AP * RPP == BM || row < BM) *reinterpret_cast<u32x4 *>(&As[buf][row * LDS_STRIDE + piece * 4]) = ra[p];
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             const int row = p * RPP + prow;
-            if (row < BN) *reinterpret_cast<float4 *>(&Bs[buf][row * LDS_STRIDE + piece * 4]) = rb[p];
+            if (BP * RPP == BN || row < BN) *reinterpret_cast<u32x4 *>(&Bs[buf][row * LDS_STRIDE + piece * 4]) = rb[p];
         }
     };
 
@@ -179,35 +204,44 @@ __global__ __launch_bounds__(kThreads) void conv_gemm_f32_kernel(const ConvArgs 
     const int a_row0 = wave_m * (32 * WM) + frag_row;
     const int b_row0 = wave_n * (32 * WN) + frag_row;
 
+    auto compute = [&](int buf, int kb) {
+        float4 fa[WM], fb[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+            fa[i] = *reinterpret_cast<const float4 *>(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+            }
+    };
+
     load_chunk(kc_begin);
     store_chunk(0);
     __syncthreads();
 
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-        const int buf = (kc - kc_begin) & 1;
-        if (kc + 1 < kc_end) load_chunk(kc + 1);
+    int buf = 0;
+    for (int kc = kc_begin; kc + 1 < kc_end; ++kc) {
+        load_chunk(kc + 1);                       // lands while the MFMAs of this chunk run
+        __builtin_amdgcn_sched_barrier(0);        // keep the loads up here: the scheduler otherwise sinks them to their use
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            float4 fa[WM], fb[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k]);
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-                fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k]);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kc + 1 < kc_end) store_chunk(buf ^ 1);
+        for (int kb = 0; kb < BK / 8 - 1; ++kb) compute(buf, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        // the other buffer was last read before the barrier that ended the previous iteration
+        store_chunk(buf ^ 1);
+        compute(buf, BK / 8 - 1);
         __syncthreads();
+        buf ^= 1;
     }
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) compute(buf, kb);
 
     // ---- epilogue.  Lane holds channel (lane&31) of tile column j; register r is tile row
     //      (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -399,7 +433,7 @@ int launch(const char *name, ConvArgs a, int splits, hipStream_t s) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     a.mtiles = (int)((a.M + BM - 1) / BM);
     a.ntiles = (a.Cout + BN - 1) / BN;
-    dim3 grid(a.mtiles * a.ntiles, splits), block(kThreads);
+    dim3 grid(a.mtiles * a.ntiles, splits), block(64 * WAVES_M * WAVES_N);
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
     const double K = (double)TAPS * a.Cin;
     const double out_rows = POOL ? (double)a.M / 4 : (double)a.M;
@@ -460,6 +494,18 @@ extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const fl
         return ty1::fail("ty1_conv3x3: Cin=%d needs Cout %% 32 == 0 (got %d)", Cin, Cout);
     }
     const long long tiles128 = ((a.M + 127) / 128) * ((Cout + 127) / 128);
+    static const char *exp_cfg = getenv("TY1_EXP");
+    if (exp_cfg && Cout % 128 == 0) {
+        if (!strcmp(exp_cfg, "w8"))
+            return pool ? launch<2, 1, 2, 4, 32, 9, true, false>("conv_f32_128x128w8_pool", a, 1, s)
+                        : launch<2, 1, 2, 4, 32, 9, false, false>("conv_f32_128x128w8", a, 1, s);
+        if (!strcmp(exp_cfg, "bk16"))
+            return pool ? launch<2, 2, 2, 2, 16, 9, true, false>("conv_f32_128x128bk16_pool", a, 1, s)
+                        : launch<2, 2, 2, 2, 16, 9, false, false>("conv_f32_128x128bk16", a, 1, s);
+        if (!strcmp(exp_cfg, "w8b"))
+            return pool ? launch<1, 2, 4, 2, 32, 9, true, false>("conv_f32_128x128w8b_pool", a, 1, s)
+                        : launch<1, 2, 4, 2, 32, 9, false, false>("conv_f32_128x128w8b", a, 1, s);
+    }
     if (Cout % 128 == 0 && tiles128 >= 512)
         return pool ? launch<2, 2, 2, 2, 32, 9, true, false>("conv_f32_128x128_pool", a, 1, s)
                     : launch<2, 2, 2, 2, 32, 9, false, false>("conv_f32_128x128", a, 1, s);
