@@ -56,6 +56,20 @@ int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const float *scale,
                              ty1_stream_t stream);
 
 /*
+ * Same block with a caller-provided scratch workspace (device memory, 16-byte aligned).  With it, the
+ * last partial round of output tiles is split along K into short blocks that fill every CU, and a
+ * fix-up kernel sums the partial tiles and applies the epilogue (see csrc/conv_gemm.hip); results are
+ * the same function of the inputs up to the f32 summation order of those tiles.  A NULL or too small
+ * workspace selects the plain single-grid path.  ty1_conv3x3_workspace_bytes reports the size the
+ * given problem wants (0 when it would not split).  No counterpart in the reference (Keras owns its
+ * scratch memory).
+ */
+int ty1_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout, int pool, size_t *bytes);
+int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *scale, const float *shift,
+                                float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                                void *workspace, size_t workspace_bytes, ty1_stream_t stream);
+
+/*
  * Split-K Dense: part[s][n][u] = sum_{k in slice s} x[n][k] * wt[u][k]      (no bias here)
  * Replaces the matmul of Flatten + Dense(1470,'linear',name='connected_0'):
  * /root/reference/models/model_tiny_yolov1.py:89,96.  The bias add and the split-K reduction
@@ -166,6 +180,13 @@ int ty1_prof_reset(void);
 int ty1_prof_query(const char *prefix, int *launches, double *total_ms);
 /* Writes up to cap bytes of "name launches total_ms\n" lines for every kernel seen. */
 int ty1_prof_dump(char *buf, size_t cap);
+
+/*
+ * Developer hook (no reference counterpart): when buf != NULL, every later conv/dense GEMM launch with
+ * at most cap_blocks workgroups writes 8 int64 per workgroup: s_memrealtime (100 MHz) at start, after the
+ * prologue, after the K loop, at the end; HW_ID; XCC_ID.  Pass NULL to switch it off.
+ */
+int ty1_debug_stamp_buffer(long long *buf, long long cap_blocks);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ def test_decode_nms_edge_cases():
 
 
 # ------------------------------------------------------------------------------- conv blocks
-def _conv_case(N, H, cin, cout, pool, seed):
+def _conv_case(N, H, cin, cout, pool, seed, use_ws=False):
     rng = np.random.default_rng(seed)
     x = rng.random((N, H, H, cin)).astype(np.float32)
     w = P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)
@@ -114,7 +114,11 @@ def _conv_case(N, H, cin, cout, pool, seed):
     xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
     ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
     scale, shift = ops.fold_bn(gamma, beta, mean, var)
-    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool).cpu().numpy()
+    ws = None
+    if use_ws:      # the K-split tail path (csrc/conv_gemm.hip plan_tail); poison the scratch to catch unwritten partials
+        nbytes = ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool)
+        ws = torch.full((max(nbytes, 16) // 4,), float('nan'), dtype=torch.float32, device=DEV)
+    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool, workspace=ws).cpu().numpy()
     return got, ref
 
 
@@ -125,9 +129,16 @@ LAYERS = [(2, 448, 3, 16, True), (2, 224, 16, 32, True), (2, 112, 32, 64, True),
           (1, 6, 64, 128, False), (70, 7, 64, 64, False)]
 
 
-@pytest.mark.parametrize('N,H,cin,cout,pool', LAYERS)
-def test_conv_block_vs_oracle(N, H, cin, cout, pool):
-    got, ref = _conv_case(N, H, cin, cout, pool, seed=cin + cout)
+# whole tiles + K-split tail (294 tiles on 256 CUs), and a deep-K 7x7 layer that is all tail
+SPLIT_LAYERS = [(24, 28, 128, 256, True), (12, 7, 1024, 256, False)]
+
+
+@pytest.mark.parametrize('use_ws', [False, True])
+@pytest.mark.parametrize('N,H,cin,cout,pool', LAYERS + SPLIT_LAYERS)
+def test_conv_block_vs_oracle(N, H, cin, cout, pool, use_ws):
+    if use_ws and cin == 3:
+        pytest.skip('first layer has no split path')
+    got, ref = _conv_case(N, H, cin, cout, pool, seed=cin + cout, use_ws=use_ws)
     assert got.shape == ref.shape
     # fp32 bar of north_star: 1e-3 relative.  Measured error is ~1e-6 (exact-f32 MFMA, fp32 accumulate).
     np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-5)

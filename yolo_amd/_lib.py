@@ -13,6 +13,8 @@ _vp, _i, _f, _d, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_int
 SIGNATURES = {
     'ty1_fold_bn': [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     'ty1_conv3x3_bn_leaky_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    'ty1_conv3x3_workspace_bytes': [_i, _i, _i, _i, _i, _i, _vp],
+    'ty1_conv3x3_bn_leaky_ws_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _c.c_size_t, _vp],
     'ty1_dense_splitk_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_head_activate_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_decode_nms': [_vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
@@ -28,6 +30,7 @@ SIGNATURES = {
     'ty1_prof_reset': [],
     'ty1_prof_query': [_c.c_char_p, _c.POINTER(_i), _c.POINTER(_d)],
     'ty1_prof_dump': [_c.c_char_p, _c.c_size_t],
+    'ty1_debug_stamp_buffer': [_vp, _i64],
     'ty1_version': [],
 }
 

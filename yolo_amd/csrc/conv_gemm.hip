@@ -15,8 +15,19 @@
 // Block: 256 threads = 4 waves (WAVES_M x WAVES_N), each wave WM x WN tiles of 32x32.
 // K loop: chunks of BK floats, double-buffered in LDS (row stride BK+4 floats: conflict-free for
 // the ds_read_b128 16-lane groups), next chunk prefetched into registers during the MFMAs.
+//
+// Grid quantisation.  Every tile of a layer costs the same, two tiles share a CU, and the tile
+// count of this network is always 49 * 2^k: a plain grid leaves up to a quarter of the chip idle in
+// its last round (784 tiles on 256 CUs = 3.06 rounds).  A layer is therefore run as
+//   (1) the largest multiple of the CU count of whole tiles, fused epilogue, then
+//   (2) the remaining R < #CU tiles split s ways along K (R*s ~ a multiple of #CU short blocks that
+//       write raw accumulator tiles to a caller-provided workspace), then
+//   (3) a small fix-up kernel that sums the s partials and applies BN/LeakyReLU/max-pool.
+// plan_tail() picks s with a cost model in units of one K chunk; without a workspace the layer runs
+// as one plain grid (same results, slower tail).
 #include "common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -26,21 +37,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 
+enum : int { kFused = 0, kDenseRaw = 1, kTileRaw = 2 };
+
 struct ConvArgs {
     const float *x;      // A source: NHWC input (conv) or [M][K] row-major (dense)
     const float *w;      // [Nvalid rows][ldw] weights, k contiguous
     const float *scale;  // per output channel (conv epilogue)
     const float *shift;
-    float *y;            // output
+    float *y;            // output (kFused), dense partials (kDenseRaw) or tile partials (kTileRaw)
     int NB, H, W, Cin;   // input geometry (dense: H=W=1, Cin=K)
     int Cout;            // GEMM N (valid rows of w)
     int ldw;             // row stride of w in floats
     int ldy;             // dense: row stride of the output partials
-    long long M;         // GEMM rows (pre-pool pixels or dense batch rows)
-    int chunks_per_split;
+    int M;               // GEMM rows (pre-pool pixels or dense batch rows)
+    int chunks_total;    // K / BK
+    int splits;          // gridDim.y: block (.., s) reduces chunks [chunks_total*s/splits, chunks_total*(s+1)/splits)
     float alpha;
     int mtiles, ntiles;
+    int tile_begin;      // this launch covers logical tiles [tile_begin, tile_begin + gridDim.x)
+    long long *stamp;    // developer timeline buffer (8 x i64 per block) or nullptr
+    long long stamp_cap; // rows of 8 i64 in stamp
+    int stagger;         // first-round blocks in odd wave slots sleep stagger * 8128 cycles (phase offset of CU partners)
+    int first_round;     // number of blocks that start together (2 per CU)
 };
+
+long long *g_stamp = nullptr;     // set by ty1_debug_stamp_buffer (developer tool, tools/stamp_trace.py)
+long long g_stamp_cap = 0;
+
+__device__ __forceinline__ void stamp(const ConvArgs &a, int slot) {
+    if (a.stamp && threadIdx.x == 0) {
+        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 1 || slot == 2)
+            a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5 + slot] = __builtin_amdgcn_s_memtime();
+    }
+}
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (private L2), so give every XCD a
 // contiguous range of logical tile ids (neighbouring tiles share halo rows and weight panels).
@@ -50,7 +80,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, bool RAW>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, int MODE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(const ConvArgs a) {
     static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per block");
     constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
@@ -67,14 +97,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
-    // Two blocks share a CU, i.e. two waves share each SIMD's matrix pipe.  Running the same program at
-    // equal priority they fall into lockstep and stall together at every barrier / LDS-store phase.
-    // Give the wave in the odd hardware wave slot a higher static priority: it issues whenever it can,
-    // the partner fills its gaps, and the two drift apart.  (HW_REG_HW_ID[3:0] = wave slot on the SIMD.)
-    if (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) __builtin_amdgcn_s_setprio(1);
-
-    const int nwg = a.mtiles * a.ntiles;
-    const int logical = xcd_remap(blockIdx.x, nwg);
+    stamp(a, 0);
+    if (a.stamp && threadIdx.x == 0) {
+        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+    const int tile_local = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical = a.tile_begin + tile_local;
     const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
     const int split = blockIdx.y;
 
@@ -85,15 +114,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     //      the scheduler can interleave with the MFMAs).  Offsets are 32-bit bytes relative to the first
     //      image this block touches, so tensors larger than 4 GiB still work.
     constexpr unsigned kOOB = 0xFFFFFFFFu;
-    const long long m_first = (long long)mt * BM;
+    const int m_first = mt * BM;
     long long a_origin;                       // element offset of the block's buffer base inside x
     if (TAPS == 1) {
-        a_origin = m_first * a.Cin;
+        a_origin = (long long)m_first * a.Cin;
     } else {
-        const long long pix = POOL ? (m_first >> 2) / ((a.H >> 1) * (a.W >> 1)) : m_first / ((long long)a.H * a.W);
-        a_origin = pix * a.H * a.W * a.Cin;
+        const int img = POOL ? (m_first >> 2) / ((a.H >> 1) * (a.W >> 1)) : m_first / (a.H * a.W);
+        a_origin = (long long)img * a.H * a.W * a.Cin;
     }
-    const long long a_total = (TAPS == 1 ? a.M : (long long)a.NB * a.H * a.W) * a.Cin;
+    // block-uniform by construction; say so, or the buffer resource below is treated as divergent (waterfall loops)
+    a_origin = ((long long)__builtin_amdgcn_readfirstlane((int)(a_origin >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)a_origin);
+    const long long a_total = (TAPS == 1 ? (long long)a.M : (long long)a.NB * a.H * a.W) * a.Cin;
     const long long a_left = (a_total - a_origin) * 4;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(a.x + a_origin), 0, (int)(a_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_left), 0x00020000);
@@ -105,7 +137,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         const int row = p * RPP + prow;
-        const long long m = m_first + row;
+        const int m = m_first + row;
         a_base[p] = 0;
         a_mask[p] = 0;
         if (row < BM && m < a.M) {
@@ -113,24 +145,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
                 a_base[p] = (unsigned)((long long)row * a.Cin * 4);
                 a_mask[p] = 1;
             } else {
-                long long n;
-                int yy, xx;
+                int n, yy, xx;
                 if (POOL) {
                     const int Hp = a.H >> 1, Wp = a.W >> 1;
-                    const long long win = m >> 2;
-                    const int q = (int)(m & 3);
+                    const int win = m >> 2, q = m & 3;
                     n = win / (Hp * Wp);
-                    const int rem = (int)(win - n * (Hp * Wp));
+                    const int rem = win - n * (Hp * Wp);
                     const int py = rem / Wp, px = rem - py * Wp;
                     yy = 2 * py + (q >> 1);
                     xx = 2 * px + (q & 1);
                 } else {
                     n = m / (a.H * a.W);
-                    const int rem = (int)(m - n * (a.H * a.W));
+                    const int rem = m - n * (a.H * a.W);
                     yy = rem / a.W;
                     xx = rem - yy * a.W;
                 }
-                const long long el = ((n * a.H + yy) * a.W + xx) * a.Cin - a_origin;
+                const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - a_origin;
                 a_base[p] = (unsigned)(el * 4);
                 unsigned mask = 0;
 #pragma unroll
@@ -151,32 +181,39 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     }
 
     const int chunks_per_tap = a.Cin / BK;
-    const int kc_begin = split * a.chunks_per_split;
-    const int kc_end = kc_begin + a.chunks_per_split;
+    const int kc_begin = (int)((long long)a.chunks_total * split / a.splits);
+    const int kc_end = (int)((long long)a.chunks_total * (split + 1) / a.splits);
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[AP], rb[BP];
-    auto load_chunk = [&](int kc) {
-        int tap, ci0;
-        if (TAPS == 1) {
-            tap = 0;
-            ci0 = kc * BK;
-        } else {
-            tap = kc / chunks_per_tap;
-            ci0 = (kc - tap * chunks_per_tap) * BK;
-        }
-        const int dy = TAPS == 1 ? 0 : tap / 3 - 1, dx = TAPS == 1 ? 0 : tap % 3 - 1;
-        const int delta = (((dy * a.W + dx) * a.Cin) + ci0 + piece * 4) * 4;      // bytes, may be negative
+    // fetch cursor: chunk ld_kc = (tap ld_tap, channel offset ld_ci0); advanced incrementally (no division in the loop)
+    int ld_kc = kc_begin, ld_tap = 0, ld_ci0 = kc_begin * BK;
+    if (TAPS != 1) {
+        ld_tap = kc_begin / chunks_per_tap;
+        ld_ci0 = (kc_begin - ld_tap * chunks_per_tap) * BK;
+    }
+    auto load_chunk = [&]() {                 // past kc_end every lane goes out of range and nothing is fetched
+        const bool live = ld_kc < kc_end;
+        const int dy = TAPS == 1 ? 0 : ld_tap / 3 - 1, dx = TAPS == 1 ? 0 : ld_tap - 3 * (ld_tap / 3) - 1;
+        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0 + piece * 4) * 4;   // bytes, may be negative
+        const unsigned tapbit = live ? 1u << ld_tap : 0u;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const unsigned off = ((a_mask[p] >> tap) & 1u) ? a_base[p] + (unsigned)delta : kOOB;
+            const unsigned off = (a_mask[p] & tapbit) ? a_base[p] + (unsigned)delta : kOOB;
             ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
         }
-        const unsigned koff = (unsigned)(kc * BK + piece * 4) * 4u;
+        const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
-            const unsigned off = b_base[p] == kOOB ? kOOB : b_base[p] + koff;
+            const unsigned off = (b_base[p] == kOOB || !live) ? kOOB : b_base[p] + koff;
             rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
+        }
+        ++ld_kc;
+        ld_ci0 += BK;
+        if (TAPS != 1) {                          // branch-free wrap to the next tap
+            const bool wrap = ld_ci0 == a.Cin;
+            ld_ci0 = wrap ? 0 : ld_ci0;
+            ld_tap += wrap ? 1 : 0;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -204,66 +241,129 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     const int a_row0 = wave_m * (32 * WM) + frag_row;
     const int b_row0 = wave_n * (32 * WN) + frag_row;
 
-    auto compute = [&](int buf, int kb) {
-        float4 fa[WM], fb[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-            fa[i] = *reinterpret_cast<const float4 *>(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k]);
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-            fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k]);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-            }
+    // One k-block (8 k values: each lane holds 4 of them, the MFMA pairs lane halves) of A and B fragments.
+    struct Frag {
+        float a[WM][4], b[WN][4];
     };
+    auto read_frag = [&](Frag &f, int buf, int kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k], 16));
+            f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k], 16));
+            f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
+        }
+    };
+    auto mfma = [&](const Frag &f, int k0, int k1) {        // WM*WN*(k1-k0) MFMAs
+#pragma unroll
+        for (int k = k0; k < k1; ++k)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NKB = BK / 8;
+    static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
-    load_chunk(kc_begin);
+    if (a.stagger > 0 && (int)blockIdx.x < a.first_round && (int)blockIdx.x >= a.first_round / 2)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    load_chunk();
     store_chunk(0);
+    load_chunk();                                 // chunk kc_begin + 1 (nothing if the range has one chunk)
     __syncthreads();
+    stamp(a, 1);
 
+    // Software pipeline of one wave (the matrix pipe should never wait for this wave's own memory work).
+    // Per chunk, right after the barrier that published it:
+    //   1. read the fragments of its first k-block                (latency hidden by 2.)
+    //   2. store the NEXT chunk (fetched a whole chunk ago) to the other LDS buffer and immediately re-issue
+    //      the fetch of the chunk after that into the same registers; the 32 KB of LDS stores per block
+    //      (the VGPR->LDS path moves ~79 B/clk per CU) drain behind the MFMAs that follow
+    //   3. the second half of the previous chunk's last k-block (8 MFMAs kept back across the barrier)
+    //   4. k-blocks 0..NKB-1 with the fragments of k-block kb+1 read while k-block kb multiplies
+    //   5. barrier with half of the last k-block still to issue.
+    Frag f0, f1;
+    auto kblocks = [&](int buf, int tail) {       // k-blocks 0..NKB-1 of one chunk; the last one multiplies k < tail only
+        read_frag(f1, buf, 1);
+        mfma(f0, 0, 4);
+        if (NKB == 4) {
+            read_frag(f0, buf, 2);
+            mfma(f1, 0, 4);
+            read_frag(f1, buf, 3);
+            mfma(f0, 0, 4);
+        }
+        mfma(f1, 0, tail);
+    };
+    // The loop body is the same for every chunk (one basic block, no peeling: peeled copies make the register
+    // allocator shuffle the 64 accumulator registers around the loop).  The first pass multiplies a zero
+    // fragment in step 3, the last pass stores / fetches nothing real (the fetch cursor is past kc_end).
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f1.b[j][k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f1.a[i][k] = 0.f;
     int buf = 0;
-    for (int kc = kc_begin; kc + 1 < kc_end; ++kc) {
-        load_chunk(kc + 1);                       // lands while the MFMAs of this chunk run
-        __builtin_amdgcn_sched_barrier(0);        // keep the loads up here: the scheduler otherwise sinks them to their use
-#pragma unroll
-        for (int kb = 0; kb < BK / 8 - 1; ++kb) compute(buf, kb);
+    read_frag(f0, 0, 0);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        store_chunk(buf ^ 1);                     // that buffer was last read before the previous barrier
+        load_chunk();
+        mfma(f1, 2, 4);
+        kblocks(buf, 2);
         __builtin_amdgcn_sched_barrier(0);
-        // the other buffer was last read before the barrier that ended the previous iteration
-        store_chunk(buf ^ 1);
-        compute(buf, BK / 8 - 1);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         buf ^= 1;
+        read_frag(f0, buf, 0);
     }
-#pragma unroll
-    for (int kb = 0; kb < BK / 8; ++kb) compute(buf, kb);
+    mfma(f1, 2, 4);
 
+    stamp(a, 2);
     // ---- epilogue.  Lane holds channel (lane&31) of tile column j; register r is tile row
     //      (r&3) + 8*(r>>2) + 4*(lane>>5).
     const int h = lane >> 5;
+    if (MODE == kTileRaw) {
+        // raw accumulator tile -> workspace [split][tile_local][BM][BN]; fixed up by conv_fixup_kernel
+        float *out = a.y + ((long long)split * gridDim.x + tile_local) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = wave_n * (32 * WN) + 32 * j + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int row0 = wave_m * (32 * WM) + 32 * i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + col] = acc[i][j][r];
+            }
+        }
+        stamp(a, 3);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int n = nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
         if (n >= a.Cout) continue;
         float sc = 1.f, sh = 0.f;
-        if (!RAW) {
+        if (MODE == kFused) {
             sc = a.scale[n];
             sh = a.shift[n];
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
-            const long long m0 = (long long)mt * BM + wave_m * (32 * WM) + 32 * i;
-            if (RAW) {
+            const int m0 = mt * BM + wave_m * (32 * WM) + 32 * i;
+            if (MODE == kDenseRaw) {
                 float *out = a.y + (long long)split * a.M * a.ldy;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < a.M) out[m * a.ldy + n] = acc[i][j][r];
+                    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < a.M) out[(long long)m * a.ldy + n] = acc[i][j][r];
                 }
             } else if (POOL) {
 #pragma unroll
@@ -275,18 +375,73 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
                         v[q] = t > 0.f ? t : t * a.alpha;
                     }
                     const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    const long long win = (m0 >> 2) + 2 * g + h;
-                    if (win * 4 < a.M) a.y[win * a.Cout + n] = pooled;
+                    const int win = (m0 >> 2) + 2 * g + h;
+                    if (win * 4 < a.M) a.y[(long long)win * a.Cout + n] = pooled;
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     float t = acc[i][j][r] * sc + sh;
                     t = t > 0.f ? t : t * a.alpha;
-                    if (m < a.M) a.y[m * a.Cout + n] = t;
+                    if (m < a.M) a.y[(long long)m * a.Cout + n] = t;
                 }
             }
+        }
+    }
+    stamp(a, 3);
+}
+
+// Fix-up of the K-split tail tiles: y = [pool](leaky(sum_s part[s] * scale + shift)).
+// part is [splits][tiles][BM][BN] (tile-local rows, pooled layers in window-major order m = 4*window + q).
+// One block per tile; a thread owns four consecutive channels of one output row (pool: of one window).
+template <int BM, int BN, bool POOL>
+__global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict__ part, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, float *__restrict__ y,
+                                                         int M, int Cout, int ntiles, int tile_begin, int tiles,
+                                                         int splits, float alpha) {
+    const int tile_local = blockIdx.x;
+    const int logical = tile_begin + tile_local;
+    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    constexpr int ROWS = POOL ? BM / 4 : BM, C4 = BN / 4;
+    const long long split_stride = (long long)tiles * BM * BN;
+    const float *base = part + (long long)tile_local * BM * BN;
+    for (int idx = threadIdx.x; idx < ROWS * C4; idx += 256) {
+        const int r = idx / C4, c = (idx - r * C4) * 4;
+        const int n = nt * BN + c;
+        if (n >= Cout) continue;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + n), sh = *reinterpret_cast<const float4 *>(shift + n);
+        float4 res;
+        if (POOL) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s = 0; s < splits; ++s) {
+                    const float4 p4 = *reinterpret_cast<const float4 *>(base + s * split_stride + (4 * r + q) * BN + c);
+                    s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
+                }
+                s4.x = s4.x * sc.x + sh.x; s4.y = s4.y * sc.y + sh.y; s4.z = s4.z * sc.z + sh.z; s4.w = s4.w * sc.w + sh.w;
+                v[q].x = s4.x > 0.f ? s4.x : s4.x * alpha; v[q].y = s4.y > 0.f ? s4.y : s4.y * alpha;
+                v[q].z = s4.z > 0.f ? s4.z : s4.z * alpha; v[q].w = s4.w > 0.f ? s4.w : s4.w * alpha;
+            }
+            res.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
+            res.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
+            res.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
+            res.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
+            const int win = mt * (BM / 4) + r;
+            if (win * 4 < M) *reinterpret_cast<float4 *>(y + (long long)win * Cout + n) = res;
+        } else {
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < splits; ++s) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(base + s * split_stride + r * BN + c);
+                s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
+            }
+            s4.x = s4.x * sc.x + sh.x; s4.y = s4.y * sc.y + sh.y; s4.z = s4.z * sc.z + sh.z; s4.w = s4.w * sc.w + sh.w;
+            res.x = s4.x > 0.f ? s4.x : s4.x * alpha; res.y = s4.y > 0.f ? s4.y : s4.y * alpha;
+            res.z = s4.z > 0.f ? s4.z : s4.z * alpha; res.w = s4.w > 0.f ? s4.w : s4.w * alpha;
+            const int m = mt * BM + r;
+            if (m < M) *reinterpret_cast<float4 *>(y + (long long)m * Cout + n) = res;
         }
     }
 }
@@ -428,38 +583,119 @@ void launch_c3(int nt, dim3 grid, hipStream_t s, const float *x, const float *w,
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, bool RAW>
-int launch(const char *name, ConvArgs a, int splits, hipStream_t s) {
-    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    a.mtiles = (int)((a.M + BM - 1) / BM);
-    a.ntiles = (a.Cout + BN - 1) / BN;
-    dim3 grid(a.mtiles * a.ntiles, splits), block(64 * WAVES_M * WAVES_N);
-    // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
-    const double K = (double)TAPS * a.Cin;
-    const double out_rows = POOL ? (double)a.M / 4 : (double)a.M;
+int num_cus() {
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            return n;
+        return 256;
+    }();
+    return cus;
+}
+
+// How to run T equal tiles of C chunks each on `slots` CUs (see the header comment).  Costs are in chunk-times
+// of one CU: a tile costs C, every block pays a fixed `ovh` (prologue, first fetch, epilogue), the two extra
+// launches and the partial round trip cost `fix`.
+struct TailPlan {
+    int whole, rem, splits;
+};
+TailPlan plan_tail(int T, int C, int slots) {
+    TailPlan p{T, 0, 1};
+    static const char *off = getenv("TY1_NO_TAIL_SPLIT");
+    if (off || T % slots == 0 || C < 2) return p;
+    const double ovh = 3.0, fix = 4.0;
+    double best = std::ceil((double)T / slots) * (C + ovh);
+    const int rem = T % slots, whole = T - rem;
+    for (int s = 2; s <= (C < 32 ? C : 32); ++s) {
+        const int per = (C + s - 1) / s;
+        const double t = (double)whole / slots * (C + ovh) + std::ceil((double)rem * s / slots) * (per + ovh) + fix;
+        if (t < 0.96 * best) {
+            best = t;
+            p = TailPlan{whole, rem, s};
+        }
+    }
+    return p;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, int MODE>
+int launch_gemm(const char *name, ConvArgs a, int tiles, int splits, double flops, double bytes, hipStream_t s) {
+    dim3 grid(tiles, splits), block(64 * WAVES_M * WAVES_N);
+    a.splits = splits;
+    a.stamp = (g_stamp && 2ll * grid.x * grid.y <= g_stamp_cap) ? g_stamp : nullptr;
+    a.stamp_cap = g_stamp_cap;
+    { static const char *sg = getenv("TY1_STAGGER"); a.stagger = sg ? atoi(sg) : 0; a.first_round = 2 * num_cus(); }
     char tag[96];
     snprintf(tag, sizeof tag, "%s@%dx%d>%d", name, a.H, a.Cin, a.Cout);
-    ty1::ProfScope prof(tag, s, 2.0 * (double)a.M * a.Cout * K,
-                        4.0 * ((double)a.M * a.Cin + (double)a.Cout * K + out_rows * a.Cout * (RAW ? splits : 1)));
-    conv_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, BK, TAPS, POOL, RAW><<<grid, block, 0, s>>>(a);
+    ty1::ProfScope prof(tag, s, flops, bytes);
+    static const char *pad = getenv("TY1_LDS_PAD");          // developer: extra dynamic LDS bytes (lowers occupancy)
+    conv_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, BK, TAPS, POOL, MODE><<<grid, block, pad ? atoi(pad) : 0, s>>>(a);
     return ty1::check_launch(name);
 }
 
-}  // namespace
+// One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: whole tiles, K-split tail, fix-up.
+// ws == nullptr: size query only (returns the workspace bytes the plan needs through *ws_need).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL>
+int run_conv(const char *name, ConvArgs a, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    a.chunks_total = 9 * a.Cin / BK;
+    const int T = a.mtiles * a.ntiles;
+    TailPlan p = plan_tail(T, a.chunks_total, num_cus());
+    const size_t need = (size_t)p.rem * p.splits * BM * BN * sizeof(float);
+    if (ws_need) {
+        *ws_need = p.rem ? need : 0;
+        return 0;
+    }
+    if (p.rem && (!ws || ws_bytes < need)) p = TailPlan{T, 0, 1};     // no workspace: one plain grid
+    // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
+    const double K = 9.0 * a.Cin, out_rows = POOL ? a.M / 4.0 : (double)a.M;
+    const double flops = 2.0 * a.M * a.Cout * K, bytes = 4.0 * ((double)a.M * a.Cin + a.Cout * K + out_rows * a.Cout);
+    char nm[64];
+    if (p.whole) {
+        a.tile_begin = 0;
+        const double f = (double)p.whole / T;
+        snprintf(nm, sizeof nm, "conv_f32_%s%s", name, POOL ? "_pool" : "");
+        if (int rc = launch_gemm<WM, WN, WAVES_M, WAVES_N, BK, 9, POOL, kFused>(nm, a, p.whole, 1, flops * f, bytes * f, s)) return rc;
+    }
+    if (p.rem) {
+        ConvArgs t = a;
+        t.tile_begin = p.whole;
+        t.y = ws;
+        const double f = (double)p.rem / T;
+        snprintf(nm, sizeof nm, "conv_f32_%s_tail", name);
+        if (int rc = launch_gemm<WM, WN, WAVES_M, WAVES_N, BK, 9, POOL, kTileRaw>(nm, t, p.rem, p.splits, flops * f, bytes * f, s))
+            return rc;
+        char tag[96];
+        snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", a.H, a.Cin, a.Cout);
+        ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
+        conv_fixup_kernel<BM, BN, POOL><<<p.rem, 256, 0, s>>>(ws, a.scale, a.shift, a.y, a.M, a.Cout, a.ntiles, p.whole, p.rem,
+                                                              p.splits, a.alpha);
+        return ty1::check_launch("conv_fixup");
+    }
+    return 0;
+}
 
-extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const float *scale, const float *shift,
-                                        float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
-                                        ty1_stream_t stream) {
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+int run_conv_p(const char *name, bool pool, const ConvArgs &a, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
+    return pool ? run_conv<WM, WN, WAVES_M, WAVES_N, BK, true>(name, a, ws, ws_bytes, ws_need, s)
+                : run_conv<WM, WN, WAVES_M, WAVES_N, BK, false>(name, a, ws, ws_bytes, ws_need, s);
+}
+
+// Shared by the launch and the workspace query.  ws_need != nullptr: query only.
+int conv3x3_dispatch(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H, int W,
+                     int Cin, int Cout, int pool, float alpha, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
     TY1_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ty1_conv3x3: bad dimensions");
+    if (ws_need) *ws_need = 0;
     if (N == 0) return 0;
-    TY1_REQUIRE(x && w && scale && shift && y, "ty1_conv3x3: null pointer");
     TY1_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "ty1_conv3x3: pool needs even H, W (got %dx%d)", H, W);
     TY1_REQUIRE(Cout % 16 == 0, "ty1_conv3x3: Cout=%d must be a multiple of 16", Cout);
-    TY1_REQUIRE((long long)N * H * W * Cout < (1ll << 40), "ty1_conv3x3: tensor too large");
-    hipStream_t s = (hipStream_t)stream;
+    TY1_REQUIRE((long long)N * H * W < (1ll << 31) - 256, "ty1_conv3x3: N*H*W must be below 2^31");
+    if (!ws_need) TY1_REQUIRE(x && w && scale && shift && y, "ty1_conv3x3: null pointer");
 
     if (Cin == 3) {
         TY1_REQUIRE(Cout <= 64, "ty1_conv3x3: Cin=3 path supports Cout <= 64 (got %d)", Cout);
+        if (ws_need) return 0;
         const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
         TY1_REQUIRE((long long)N * tiles < (1ll << 31), "ty1_conv3x3: grid too large");
         dim3 grid((unsigned)(N * tiles));
@@ -474,53 +710,64 @@ extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const fl
     }
 
     TY1_REQUIRE(Cin % 16 == 0, "ty1_conv3x3: Cin=%d must be 3 or a multiple of 16", Cin);
-    TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "ty1_conv3x3: x and w must be 16-byte aligned");
+    if (!ws_need)
+        TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)ws & 15) == 0,
+                    "ty1_conv3x3: x, w and workspace must be 16-byte aligned");
     ConvArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = 9 * Cin; a.ldy = Cout;
-    a.M = (long long)N * H * W;
+    a.M = N * H * W;
     a.alpha = alpha;
-    const bool bk32 = Cin % 32 == 0;
-    a.chunks_per_split = 9 * Cin / (bk32 ? 32 : 16);
+    const bool p = pool != 0;
 
-    // tile choice: keep BN <= Cout, and prefer >= 2 blocks per CU
-    if (!bk32) {                      // Cin == 16 (48, 80 ...): BK = 16
-        if (Cout % 64 == 0)
-            return pool ? launch<2, 1, 2, 2, 16, 9, true, false>("conv_f32_bk16_128x64_pool", a, 1, s)
-                        : launch<2, 1, 2, 2, 16, 9, false, false>("conv_f32_bk16_128x64", a, 1, s);
-        if (Cout % 32 == 0)
-            return pool ? launch<2, 1, 4, 1, 16, 9, true, false>("conv_f32_bk16_256x32_pool", a, 1, s)
-                        : launch<2, 1, 4, 1, 16, 9, false, false>("conv_f32_bk16_256x32", a, 1, s);
+    // tile choice: keep BN <= Cout; big tiles once they fill the chip, 64x64 for the 7x7 layers
+    if (Cin % 32 != 0) {              // Cin == 16 (48, 80 ...): BK = 16
+        if (Cout % 64 == 0) return run_conv_p<2, 1, 2, 2, 16>("bk16_128x64", p, a, ws, ws_bytes, ws_need, s);
+        if (Cout % 32 == 0) return run_conv_p<2, 1, 4, 1, 16>("bk16_256x32", p, a, ws, ws_bytes, ws_need, s);
         return ty1::fail("ty1_conv3x3: Cin=%d needs Cout %% 32 == 0 (got %d)", Cin, Cout);
     }
-    const long long tiles128 = ((a.M + 127) / 128) * ((Cout + 127) / 128);
-    static const char *exp_cfg = getenv("TY1_EXP");
-    if (exp_cfg && Cout % 128 == 0) {
-        if (!strcmp(exp_cfg, "w8"))
-            return pool ? launch<2, 1, 2, 4, 32, 9, true, false>("conv_f32_128x128w8_pool", a, 1, s)
-                        : launch<2, 1, 2, 4, 32, 9, false, false>("conv_f32_128x128w8", a, 1, s);
-        if (!strcmp(exp_cfg, "bk16"))
-            return pool ? launch<2, 2, 2, 2, 16, 9, true, false>("conv_f32_128x128bk16_pool", a, 1, s)
-                        : launch<2, 2, 2, 2, 16, 9, false, false>("conv_f32_128x128bk16", a, 1, s);
-        if (!strcmp(exp_cfg, "w8b"))
-            return pool ? launch<1, 2, 4, 2, 32, 9, true, false>("conv_f32_128x128w8b_pool", a, 1, s)
-                        : launch<1, 2, 4, 2, 32, 9, false, false>("conv_f32_128x128w8b", a, 1, s);
-    }
-    if (Cout % 128 == 0 && tiles128 >= 512)
-        return pool ? launch<2, 2, 2, 2, 32, 9, true, false>("conv_f32_128x128_pool", a, 1, s)
-                    : launch<2, 2, 2, 2, 32, 9, false, false>("conv_f32_128x128", a, 1, s);
+    const long long mt128 = ((long long)a.M + 127) / 128;
+    static const char *force = getenv("TY1_TILE");          // developer override
+    if (force && !strcmp(force, "128x128") && Cout % 128 == 0) return run_conv_p<2, 2, 2, 2, 32>("128x128", p, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "w8") && Cout % 128 == 0) return run_conv_p<2, 1, 2, 4, 32>("128x128w8", p, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "w8b") && Cout % 128 == 0) return run_conv_p<1, 2, 4, 2, 32>("128x128w8b", p, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "128x64") && Cout % 64 == 0) return run_conv_p<2, 1, 2, 2, 32>("128x64", p, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "64x64") && Cout % 64 == 0) return run_conv_p<1, 1, 2, 2, 32>("64x64", p, a, ws, ws_bytes, ws_need, s);
+    if (Cout % 128 == 0 && mt128 * (Cout / 128) >= 2 * num_cus())
+        return run_conv_p<2, 2, 2, 2, 32>("128x128", p, a, ws, ws_bytes, ws_need, s);
     if (Cout % 64 == 0) {
-        const long long tiles = ((a.M + 127) / 128) * (Cout / 64);
-        if (tiles >= 512 || a.M >= 4096)
-            return pool ? launch<2, 1, 2, 2, 32, 9, true, false>("conv_f32_128x64_pool", a, 1, s)
-                        : launch<2, 1, 2, 2, 32, 9, false, false>("conv_f32_128x64", a, 1, s);
-        return pool ? launch<1, 1, 2, 2, 32, 9, true, false>("conv_f32_64x64_pool", a, 1, s)
-                    : launch<1, 1, 2, 2, 32, 9, false, false>("conv_f32_64x64", a, 1, s);
+        if (mt128 * (Cout / 64) >= 2 * num_cus() || a.M >= 4096 * 2)
+            return run_conv_p<2, 1, 2, 2, 32>("128x64", p, a, ws, ws_bytes, ws_need, s);
+        return run_conv_p<1, 1, 2, 2, 32>("64x64", p, a, ws, ws_bytes, ws_need, s);
     }
-    if (Cout % 32 == 0)
-        return pool ? launch<2, 1, 4, 1, 32, 9, true, false>("conv_f32_256x32_pool", a, 1, s)
-                    : launch<2, 1, 4, 1, 32, 9, false, false>("conv_f32_256x32", a, 1, s);
+    if (Cout % 32 == 0) return run_conv_p<2, 1, 4, 1, 32>("256x32", p, a, ws, ws_bytes, ws_need, s);
     return ty1::fail("ty1_conv3x3: Cout=%d must be a multiple of 32 when Cin != 3", Cout);
+}
+
+}  // namespace
+
+extern "C" int ty1_debug_stamp_buffer(long long *buf, long long cap_blocks) {
+    g_stamp = buf;
+    g_stamp_cap = buf ? cap_blocks : 0;
+    return 0;
+}
+
+extern "C" int ty1_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout, int pool, size_t *bytes) {
+    TY1_REQUIRE(bytes, "ty1_conv3x3_workspace_bytes: null result pointer");
+    return conv3x3_dispatch(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, pool, 0.f, nullptr, 0, bytes, nullptr);
+}
+
+extern "C" int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *scale, const float *shift,
+                                           float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                                           void *workspace, size_t workspace_bytes, ty1_stream_t stream) {
+    return conv3x3_dispatch(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, (float *)workspace, workspace_bytes,
+                            nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const float *scale, const float *shift,
+                                        float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                                        ty1_stream_t stream) {
+    return conv3x3_dispatch(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, nullptr, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units, int ldk,
@@ -537,8 +784,16 @@ extern "C" int ty1_dense_splitk_f32(const float *x, const float *wt, float *part
     a.NB = N; a.H = 1; a.W = 1; a.Cin = K; a.Cout = units; a.ldw = ldk; a.ldy = ldz;
     a.M = N;
     a.alpha = 0.f;
-    a.chunks_per_split = K / 32 / splits;
+    a.chunks_total = K / 32;
+    a.tile_begin = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (N <= 32) return launch<1, 1, 1, 4, 32, 1, false, true>("dense_f32_32x128", a, splits, s);
-    return launch<1, 1, 2, 2, 32, 1, false, true>("dense_f32_64x64", a, splits, s);
+    const double flops = 2.0 * N * (double)units * K, bytes = 4.0 * ((double)N * K + (double)units * K + (double)splits * N * units);
+    if (N <= 32) {
+        a.mtiles = (N + 31) / 32;
+        a.ntiles = (units + 127) / 128;
+        return launch_gemm<1, 1, 1, 4, 32, 1, false, kDenseRaw>("dense_f32_32x128", a, a.mtiles * a.ntiles, splits, flops, bytes, s);
+    }
+    a.mtiles = (N + 63) / 64;
+    a.ntiles = (units + 63) / 64;
+    return launch_gemm<1, 1, 2, 2, 32, 1, false, kDenseRaw>("dense_f32_64x64", a, a.mtiles * a.ntiles, splits, flops, bytes, s);
 }

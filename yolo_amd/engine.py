@@ -37,15 +37,16 @@ class DeviceModel:
         ws = self._ws.get(N)
         if ws is None:
             dev, f32 = self.device, torch.float32
-            acts, h = [], self.img_size
-            for _, cout, pool in self.specs:
+            acts, h, scratch = [], self.img_size, 0
+            for cin, cout, pool in self.specs:
+                scratch = max(scratch, ops.conv3x3_workspace_bytes(N, h, h, cin, cout, pool))
                 if pool:
                     h //= 2
                 acts.append(torch.empty((N, h, h, cout), dtype=f32, device=dev))
             splits = ops.pick_splits(self.K, N, self.units)
             ldz = ops.round_up(self.units, 4)
             slots = self.S * self.S * self.B
-            ws = dict(acts=acts, part=torch.empty((splits, N, ldz), dtype=f32, device=dev),
+            ws = dict(acts=acts, scratch=torch.empty((max(scratch, 16),), dtype=torch.uint8, device=dev), part=torch.empty((splits, N, ldz), dtype=f32, device=dev),
                       y=torch.empty((N, self.S, self.S, self.C + 5 * self.B), dtype=f32, device=dev),
                       det=(torch.empty((N, slots, 4), dtype=torch.float64, device=dev),
                            torch.empty((N, slots), dtype=f32, device=dev),
@@ -59,7 +60,8 @@ class DeviceModel:
         """x (N,H,W,3) f32 NHWC on the device -> features (N, 12544) (HWC flatten)."""
         ws = ws or self.workspace(x.shape[0])
         for layer, out in zip(self.conv, ws['acts']):
-            x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out)
+            x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out,
+                                     workspace=ws['scratch'])
         return x.reshape(x.shape[0], -1)
 
     def head(self, feats, ws=None):

@@ -32,8 +32,17 @@ def fold_bn(gamma, beta, mean, var, eps=1e-3):
     return scale, shift
 
 
-def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None):
-    """x (N,H,W,Cin) NHWC f32 -> (N,H/2,W/2,Cout) if pool else (N,H,W,Cout)."""
+def conv3x3_workspace_bytes(N, H, W, Cin, Cout, pool):
+    """Scratch bytes ty1_conv3x3_bn_leaky_ws_f32 wants for this problem (0: it would not split its tail)."""
+    import ctypes
+    n = ctypes.c_size_t(0)
+    _lib.call('ty1_conv3x3_workspace_bytes', N, H, W, Cin, Cout, int(bool(pool)), ctypes.addressof(n))
+    return int(n.value)
+
+
+def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None, workspace=None):
+    """x (N,H,W,Cin) NHWC f32 -> (N,H/2,W/2,Cout) if pool else (N,H,W,Cout).
+    workspace: optional 1-D uint8/float32 device tensor used as scratch for the K-split tail."""
     _chk(x, torch.float32, 'x'); _chk(w_ohwi, torch.float32, 'w')
     _chk(scale, torch.float32, 'scale'); _chk(shift, torch.float32, 'shift')
     N, H, W, Cin = x.shape
@@ -45,8 +54,15 @@ def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None):
     else:
         _chk(out, torch.float32, 'out')
         assert tuple(out.shape) == oshape
-    _lib.call('ty1_conv3x3_bn_leaky_f32', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-              out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), _lib.current_stream())
+    if workspace is None:
+        _lib.call('ty1_conv3x3_bn_leaky_f32', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), _lib.current_stream())
+    else:
+        if not workspace.is_cuda or not workspace.is_contiguous():
+            raise ValueError('workspace must be a contiguous tensor on the GPU')
+        _lib.call('ty1_conv3x3_bn_leaky_ws_f32', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), workspace.data_ptr(),
+                  workspace.numel() * workspace.element_size(), _lib.current_stream())
     return out
 
 
