@@ -8,6 +8,7 @@ from yolo_amd import ops, _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='64,16,512,1024,0')
+ap.add_argument('--persist', action='store_true', help='stamps written by conv_persist_kernel')
 ap.add_argument('--launches', type=int, default=30)
 args = ap.parse_args()
 n, hh, cin, cout, pool = (int(v) for v in args.shape.split(','))
@@ -31,6 +32,14 @@ b = ball[:cap // 2]
 b = b[b[:, 0] != 0]
 nb = len(b)
 t0 = b[:, 0].min()
+if args.persist:
+    st, end = (b[:, 0] - t0) / 100.0, (b[:, 3] - t0) / 100.0
+    ni = np.maximum(b[:, 7], 1).astype(np.float64)
+    print(f'persistent blocks {len(b)}  span {end.max():.1f} us  items/block min {ni.min():.0f} max {ni.max():.0f}')
+    print(f'per item (shader cycles): loop {np.mean(b[:, 1] / ni):.0f}  epilogue {np.mean(b[:, 2] / ni):.0f}  rows {np.mean(b[:, 6] / ni):.0f}'
+          f'   block time {np.mean(end - st):.1f} us -> {np.mean((end - st) / ni):.2f} us per item')
+    print('end-time histogram:', np.histogram(end, bins=8)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
+    sys.exit(0)
 st, pro, loop, end = ((b[:, i] - t0) / 100.0 for i in range(4))     # microseconds
 hw = b[:, 4]
 cu = (hw >> 8) & 0xF

@@ -57,8 +57,6 @@ struct ConvArgs {
     int tile_begin;      // this launch covers logical tiles [tile_begin, tile_begin + gridDim.x)
     long long *stamp;    // developer timeline buffer (8 x i64 per block) or nullptr
     long long stamp_cap; // rows of 8 i64 in stamp
-    int stagger;         // first-round blocks in odd wave slots sleep stagger * 8128 cycles (phase offset of CU partners)
-    int first_round;     // number of blocks that start together (2 per CU)
 };
 
 long long *g_stamp = nullptr;     // set by ty1_debug_stamp_buffer (developer tool, tools/stamp_trace.py)
@@ -271,8 +269,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     constexpr int NKB = BK / 8;
     static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
-    if (a.stagger > 0 && (int)blockIdx.x < a.first_round && (int)blockIdx.x >= a.first_round / 2)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     load_chunk();
     store_chunk(0);
     load_chunk();                                 // chunk kc_begin + 1 (nothing if the range has one chunk)
@@ -392,6 +388,388 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(c
     stamp(a, 3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent conv kernel.  The grid is two workgroups per CU; workgroup b walks the work items
+// slot(b), slot(b) + G, slot(b) + 2G ... (item = output tile x K-split piece) as ONE continuous stream of
+// K chunks: the fetch cursor runs two chunks ahead of the MFMAs and simply crosses into the next item,
+// so a new tile starts with its operands already in LDS - no per-tile prologue (address arithmetic +
+// an exposed HBM round trip, 4-10 us per tile when every tile was its own workgroup) and no drain.
+// Loop body = the software pipeline described in conv_gemm_f32_kernel.  Row geometry (image, y, x of
+// every GEMM row of a tile, 3x3 validity mask) is recomputed per item with multiply-shift division.
+// ------------------------------------------------------------------------------------------------
+struct FastDiv {         // q = n / d for 0 <= n < 2^31:  (mulhi(n, M) + n) >> l
+    unsigned M, l;
+};
+FastDiv make_fastdiv(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    return FastDiv{(unsigned)(((1ull << (32 + l)) / d) + 1ull - (1ull << 32)), l};
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.M) + n) >> f.l; }
+
+struct PersistArgs {
+    const float *x, *w, *scale, *shift;
+    float *y;            // output tensor
+    float *part;         // partial tiles of the K-split tail: [split][tail tile][BM][BN]
+    int NB, H, W, Cin, Cout, M;
+    int chunks_total;
+    float alpha;
+    int ntiles;          // tiles along N
+    // work items: logical tiles [0, whole) with the fused epilogue, then the last `rem` tiles cut into `splits`
+    // K pieces each (item whole + j: tile whole + j / splits, piece j % splits) that store raw partial tiles
+    int whole, rem, splits;
+    FastDiv d_img, d_row;   // pooled layers: (H/2)*(W/2), W/2; otherwise H*W, W
+    FastDiv d_splits, d_ntiles, d_cpt;   // splits, ntiles, chunks per tap
+    long long *stamp;
+};
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel(const PersistArgs a) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    constexpr int NTHREADS = 256;
+    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int LDS_STRIDE = BK + 4;
+    constexpr int CPR = BK / 4, RPP = NTHREADS / CPR;
+    constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
+    constexpr int NKB = BK / 8;
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
+    static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int piece = tid % CPR, prow = tid / CPR;
+    const int G = gridDim.x;
+    const int items = a.whole + a.rem * a.splits;
+    if (a.stamp && tid == 0) {
+        a.stamp[(long long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        a.stamp[(long long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        a.stamp[(long long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+
+    const int chunks_per_tap = a.Cin / BK;
+    const long long x_total = (long long)a.NB * a.H * a.W * a.Cin;
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * 4), 0x00020000);
+
+    // ---- item descriptors (block-uniform scalars)
+    struct Desc {
+        int mt, nt, kc0, kc1, tap0, ci0, pslot;
+        bool live, raw;
+    };
+    auto decode = [&](int it) {
+        Desc d;
+        d.live = it < items;
+        d.raw = d.live && it >= a.whole;
+        const int j = d.raw ? it - a.whole : 0;
+        const int tail_tile = (int)fdiv((unsigned)j, a.d_splits);
+        const int split = j - tail_tile * a.splits;
+        const int logical = d.raw ? a.whole + tail_tile : (d.live ? it : 0);
+        d.mt = (int)fdiv((unsigned)logical, a.d_ntiles);
+        d.nt = logical - d.mt * a.ntiles;
+        d.kc0 = d.raw ? a.chunks_total * split / a.splits : 0;
+        d.kc1 = d.raw ? a.chunks_total * (split + 1) / a.splits : (d.live ? a.chunks_total : 0x7fffffff);
+        d.tap0 = (int)fdiv((unsigned)d.kc0, a.d_cpt);
+        d.ci0 = (d.kc0 - d.tap0 * chunks_per_tap) * BK;
+        d.pslot = split * a.rem + tail_tile;
+        // block-uniform by construction: keep them in scalar registers
+        d.mt = __builtin_amdgcn_readfirstlane(d.mt); d.nt = __builtin_amdgcn_readfirstlane(d.nt);
+        d.kc0 = __builtin_amdgcn_readfirstlane(d.kc0); d.kc1 = __builtin_amdgcn_readfirstlane(d.kc1);
+        d.tap0 = __builtin_amdgcn_readfirstlane(d.tap0); d.ci0 = __builtin_amdgcn_readfirstlane(d.ci0);
+        d.pslot = __builtin_amdgcn_readfirstlane(d.pslot);
+        return d;
+    };
+    // ---- per-item row geometry of this thread's fetch rows (buffer offsets relative to `origin`)
+    struct Rows {
+        unsigned a_base[AP], a_mask[AP], b_base[BP];
+    };
+    auto make_rows = [&](const Desc &d, Rows &R, long long &origin) {
+        const int m_first = d.mt * BM;
+        {
+            const unsigned img = __builtin_amdgcn_readfirstlane(fdiv(POOL ? (unsigned)m_first >> 2 : (unsigned)m_first, a.d_img));
+            origin = (long long)img * a.H * a.W * a.Cin;
+        }
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const int m = m_first + p * RPP + prow;
+            R.a_base[p] = 0;
+            R.a_mask[p] = 0;
+            if (d.live && m < a.M && (AP * RPP == BM || p * RPP + prow < BM)) {
+                unsigned n, yy, xx;
+                if (POOL) {
+                    const unsigned win = (unsigned)m >> 2, q = m & 3;
+                    n = fdiv(win, a.d_img);
+                    const unsigned rem = win - n * ((a.H >> 1) * (a.W >> 1));
+                    const unsigned py = fdiv(rem, a.d_row), px = rem - py * (a.W >> 1);
+                    yy = 2 * py + (q >> 1);
+                    xx = 2 * px + (q & 1);
+                } else {
+                    n = fdiv((unsigned)m, a.d_img);
+                    const unsigned rem = m - n * (a.H * a.W);
+                    yy = fdiv(rem, a.d_row);
+                    xx = rem - yy * a.W;
+                }
+                const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - origin;
+                R.a_base[p] = (unsigned)(el * 4);
+                // tap t = 3*(dy+1) + (dx+1) is inside the image: product of a row condition and a column condition
+                const unsigned rows = (yy > 0 ? 0x007u : 0u) | 0x038u | ((int)yy < a.H - 1 ? 0x1C0u : 0u);
+                const unsigned cols = (xx > 0 ? 0x049u : 0u) | 0x092u | ((int)xx < a.W - 1 ? 0x124u : 0u);
+                R.a_mask[p] = rows & cols;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            const int n = d.nt * BN + p * RPP + prow;
+            R.b_base[p] = (d.live && n < a.Cout && (BP * RPP == BN || p * RPP + prow < BN))
+                              ? (unsigned)((long long)n * 9 * a.Cin * 4) : kOOB;
+        }
+    };
+
+    // Item of this block in round r.  Full rounds of whole tiles use the XCD-aware slot (each XCD walks a
+    // contiguous range of tiles).  What is left - the last whole tiles, then the K pieces of the tail - is dealt
+    // to blocks 0, 1, 2 ... in launch order (round after round), which the dispatcher spreads over all XCDs and
+    // CUs: the blocks that get no whole tile in the partial round start on the tail pieces instead.
+    const int slot = xcd_remap(blockIdx.x, G);
+    const int full_rounds = a.whole / G, full_items = full_rounds * G;
+    auto item_of = [&](int round) {
+        if (round < full_rounds) return round * G + slot;
+        const int v = full_items + (round - full_rounds) * G + (int)blockIdx.x;
+        return v < items ? v : items;
+    };
+    int round = 0;
+    Desc cur = decode(item_of(0)), nxt = decode(item_of(1));
+    Rows rc, rn;
+    long long org_c, org_n;
+    make_rows(cur, rc, org_c);
+    make_rows(nxt, rn, org_n);
+
+    // ---- fetch cursor: two chunks ahead of the MFMAs; crosses from the current item into the next one
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[AP], rb[BP];
+    int ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
+    bool ld_next = false;
+    auto load_chunk = [&]() {
+        const bool nx = ld_next;
+        const long long org = nx ? org_n : org_c;
+        const long long left = (x_total - org) * 4;
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(a.x + org), 0, (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
+        const int t3 = ld_tap / 3;
+        const int dy = t3 - 1, dx = ld_tap - 3 * t3 - 1;
+        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0 + piece * 4) * 4;   // bytes, may be negative
+        const unsigned tapbit = 1u << ld_tap;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const unsigned base = nx ? rn.a_base[p] : rc.a_base[p];
+            const unsigned mask = nx ? rn.a_mask[p] : rc.a_mask[p];
+            const unsigned off = (mask & tapbit) ? base + (unsigned)delta : kOOB;
+            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
+        }
+        const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            const unsigned bb = nx ? rn.b_base[p] : rc.b_base[p];
+            const unsigned off = bb == kOOB ? kOOB : bb + koff;
+            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
+        }
+        ++ld_kc;
+        ld_ci0 += BK;
+        const bool wrap = ld_ci0 == a.Cin;
+        ld_ci0 = wrap ? 0 : ld_ci0;
+        ld_tap += wrap ? 1 : 0;
+        const bool cross = ld_kc == ld_end;           // branch-free hop into the next item
+        ld_kc = cross ? nxt.kc0 : ld_kc;
+        ld_end = cross ? nxt.kc1 : ld_end;
+        ld_tap = cross ? nxt.tap0 : ld_tap;
+        ld_ci0 = cross ? nxt.ci0 : ld_ci0;
+        ld_next = ld_next | cross;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p)
+            if (AP * RPP == BM || p * RPP + prow < BM)
+                *reinterpret_cast<u32x4 *>(&As[buf][(p * RPP + prow) * LDS_STRIDE + piece * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            if (BP * RPP == BN || p * RPP + prow < BN)
+                *reinterpret_cast<u32x4 *>(&Bs[buf][(p * RPP + prow) * LDS_STRIDE + piece * 4]) = rb[p];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
+    const int a_row0 = wave_m * (32 * WM) + frag_row;
+    const int b_row0 = wave_n * (32 * WN) + frag_row;
+    struct Frag {
+        float a[WM][4], b[WN][4];
+    };
+    auto read_frag = [&](Frag &f, int buf, int kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k], 16));
+            f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(
+                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k], 16));
+            f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
+        }
+    };
+    auto mfma = [&](const Frag &f, int k0, int k1) {
+#pragma unroll
+        for (int k = k0; k < k1; ++k)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+    };
+    Frag f0, f1;
+    auto zero_f1 = [&]() {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f1.b[j][k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f1.a[i][k] = 0.f;
+    };
+
+    // per-lane epilogue constants that do not depend on the item (scale / shift depend on nt only)
+    const int h = lane >> 5;
+
+    load_chunk();
+    store_chunk(0);
+    load_chunk();
+    __syncthreads();
+    zero_f1();
+    int buf = 0;
+    read_frag(f0, 0, 0);
+
+    long long t_loop = 0, t_epi = 0, t_rows = 0, n_items = 0;      // developer stamps (only when a.stamp)
+    while (cur.live) {
+        long long t0 = 0, t1 = 0, t2 = 0;
+        if (a.stamp) t0 = __builtin_amdgcn_s_memtime();
+        // BN scale / shift of this item's channels: fetched now, used in the epilogue a whole tile later
+        float sc[WN], sh[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = cur.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
+            sc[j] = (!cur.raw && n < a.Cout) ? a.scale[n] : 0.f;
+            sh[j] = (!cur.raw && n < a.Cout) ? a.shift[n] : 0.f;
+        }
+        for (int kc = cur.kc0; kc < cur.kc1; ++kc) {
+            store_chunk(buf ^ 1);                 // that buffer was last read before the previous barrier
+            load_chunk();
+            mfma(f1, 2, 4);                       // second half of the previous chunk's last k-block (zeros at an item start)
+            read_frag(f1, buf, 1);
+            mfma(f0, 0, 4);
+            if (NKB == 4) {
+                read_frag(f0, buf, 2);
+                mfma(f1, 0, 4);
+                read_frag(f1, buf, 3);
+                mfma(f0, 0, 4);
+            }
+            mfma(f1, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
+            read_frag(f0, buf, 0);                // first k-block of the next chunk (of the next item at an item end)
+        }
+        mfma(f1, 2, 4);
+        if (a.stamp) t1 = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue of item `cur`.  Lane holds channel (lane&31) of tile column j; register r is tile row
+        //      (r&3) + 8*(r>>2) + 4*(lane>>5).
+        if (cur.raw) {
+            float *out = a.part + (long long)cur.pslot * (BM * BN);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = wave_n * (32 * WN) + 32 * j + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const int row0 = wave_m * (32 * WM) + 32 * i;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + col] = acc[i][j][r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = cur.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
+                if (n < a.Cout) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        const int m0 = cur.mt * BM + wave_m * (32 * WM) + 32 * i;
+                        if (POOL) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float v[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    float t = acc[i][j][4 * g + q] * sc[j] + sh[j];
+                                    v[q] = t > 0.f ? t : t * a.alpha;
+                                }
+                                const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                                const int win = (m0 >> 2) + 2 * g + h;
+                                if (win * 4 < a.M) a.y[(long long)win * a.Cout + n] = pooled;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                float t = acc[i][j][r] * sc[j] + sh[j];
+                                t = t > 0.f ? t : t * a.alpha;
+                                if (m < a.M) a.y[(long long)m * a.Cout + n] = t;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        zero_f1();
+        if (a.stamp) t2 = __builtin_amdgcn_s_memtime();
+
+        // ---- next item becomes current; the fetch cursor is already inside it
+        ++round;
+        cur = nxt;
+        rc = rn;
+        org_c = org_n;
+        ld_next = false;
+        nxt = decode(item_of(round + 1));
+        make_rows(nxt, rn, org_n);
+        if (a.stamp) {
+            const long long t3 = __builtin_amdgcn_s_memtime();
+            t_loop += t1 - t0; t_epi += t2 - t1; t_rows += t3 - t2; ++n_items;
+        }
+    }
+    if (a.stamp && tid == 0) {
+        a.stamp[(long long)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        a.stamp[(long long)blockIdx.x * 8 + 1] = t_loop;
+        a.stamp[(long long)blockIdx.x * 8 + 2] = t_epi;
+        a.stamp[(long long)blockIdx.x * 8 + 6] = t_rows;
+        a.stamp[(long long)blockIdx.x * 8 + 7] = n_items;
+    }
+}
+
 // Fix-up of the K-split tail tiles: y = [pool](leaky(sum_s part[s] * scale + shift)).
 // part is [splits][tiles][BM][BN] (tile-local rows, pooled layers in window-major order m = 4*window + q).
 // One block per tile; a thread owns four consecutive channels of one output row (pool: of one window).
@@ -406,7 +784,7 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict
     constexpr int ROWS = POOL ? BM / 4 : BM, C4 = BN / 4;
     const long long split_stride = (long long)tiles * BM * BN;
     const float *base = part + (long long)tile_local * BM * BN;
-    for (int idx = threadIdx.x; idx < ROWS * C4; idx += 256) {
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < ROWS * C4; idx += 256 * gridDim.y) {
         const int r = idx / C4, c = (idx - r * C4) * 4;
         const int n = nt * BN + c;
         if (n >= Cout) continue;
@@ -606,7 +984,7 @@ TailPlan plan_tail(int T, int C, int slots) {
     const double ovh = 3.0, fix = 4.0;
     double best = std::ceil((double)T / slots) * (C + ovh);
     const int rem = T % slots, whole = T - rem;
-    for (int s = 2; s <= (C < 32 ? C : 32); ++s) {
+    for (int s = 2; s <= 32 && C / s >= 3; ++s) {        // a piece keeps >= 3 chunks (fetch cursor of the persistent kernel)
         const int per = (C + s - 1) / s;
         const double t = (double)whole / slots * (C + ovh) + std::ceil((double)rem * s / slots) * (per + ovh) + fix;
         if (t < 0.96 * best) {
@@ -623,7 +1001,6 @@ int launch_gemm(const char *name, ConvArgs a, int tiles, int splits, double flop
     a.splits = splits;
     a.stamp = (g_stamp && 2ll * grid.x * grid.y <= g_stamp_cap) ? g_stamp : nullptr;
     a.stamp_cap = g_stamp_cap;
-    { static const char *sg = getenv("TY1_STAGGER"); a.stagger = sg ? atoi(sg) : 0; a.first_round = 2 * num_cus(); }
     char tag[96];
     snprintf(tag, sizeof tag, "%s@%dx%d>%d", name, a.H, a.Cin, a.Cout);
     ty1::ProfScope prof(tag, s, flops, bytes);
@@ -632,45 +1009,49 @@ int launch_gemm(const char *name, ConvArgs a, int tiles, int splits, double flop
     return ty1::check_launch(name);
 }
 
-// One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: whole tiles, K-split tail, fix-up.
-// ws == nullptr: size query only (returns the workspace bytes the plan needs through *ws_need).
+// One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: one persistent launch over the whole
+// tiles and the K pieces of the tail, then the fix-up of the tail tiles.
+// ws_need != nullptr: size query only (returns the workspace bytes the plan wants).
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL>
-int run_conv(const char *name, ConvArgs a, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
+int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    a.mtiles = (a.M + BM - 1) / BM;
-    a.ntiles = (a.Cout + BN - 1) / BN;
-    a.chunks_total = 9 * a.Cin / BK;
-    const int T = a.mtiles * a.ntiles;
+    PersistArgs a{};
+    a.x = c.x; a.w = c.w; a.scale = c.scale; a.shift = c.shift; a.y = c.y; a.part = ws;
+    a.NB = c.NB; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.M = c.M;
+    a.alpha = c.alpha;
+    a.chunks_total = 9 * c.Cin / BK;
+    a.ntiles = (c.Cout + BN - 1) / BN;
+    a.d_img = make_fastdiv(POOL ? (c.H / 2) * (c.W / 2) : c.H * c.W);
+    a.d_row = make_fastdiv(POOL ? c.W / 2 : c.W);
+    a.d_ntiles = make_fastdiv(a.ntiles);
+    a.d_cpt = make_fastdiv(c.Cin / BK);
+    const int T = ((c.M + BM - 1) / BM) * a.ntiles;
     TailPlan p = plan_tail(T, a.chunks_total, num_cus());
     const size_t need = (size_t)p.rem * p.splits * BM * BN * sizeof(float);
     if (ws_need) {
         *ws_need = p.rem ? need : 0;
         return 0;
     }
-    if (p.rem && (!ws || ws_bytes < need)) p = TailPlan{T, 0, 1};     // no workspace: one plain grid
+    if (p.rem && (!ws || ws_bytes < need)) p = TailPlan{T, 0, 1};     // no workspace: whole tiles only
+    a.whole = p.whole; a.rem = p.rem; a.splits = p.splits;
+    a.d_splits = make_fastdiv(p.splits);
+    const int items = p.whole + p.rem * p.splits;
+    const int grid = items < 2 * num_cus() ? items : 2 * num_cus();
+    a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
-    const double K = 9.0 * a.Cin, out_rows = POOL ? a.M / 4.0 : (double)a.M;
-    const double flops = 2.0 * a.M * a.Cout * K, bytes = 4.0 * ((double)a.M * a.Cin + a.Cout * K + out_rows * a.Cout);
-    char nm[64];
-    if (p.whole) {
-        a.tile_begin = 0;
-        const double f = (double)p.whole / T;
-        snprintf(nm, sizeof nm, "conv_f32_%s%s", name, POOL ? "_pool" : "");
-        if (int rc = launch_gemm<WM, WN, WAVES_M, WAVES_N, BK, 9, POOL, kFused>(nm, a, p.whole, 1, flops * f, bytes * f, s)) return rc;
+    const double K = 9.0 * c.Cin, out_rows = POOL ? c.M / 4.0 : (double)c.M;
+    char tag[96];
+    {
+        snprintf(tag, sizeof tag, "conv_f32_%s%s@%dx%d>%d", name, POOL ? "_pool" : "", c.H, c.Cin, c.Cout);
+        ty1::ProfScope prof(tag, s, 2.0 * c.M * c.Cout * K, 4.0 * ((double)c.M * c.Cin + c.Cout * K + out_rows * c.Cout));
+        conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL><<<grid, 64 * WAVES_M * WAVES_N, 0, s>>>(a);
+        if (int rc = ty1::check_launch(name)) return rc;
     }
     if (p.rem) {
-        ConvArgs t = a;
-        t.tile_begin = p.whole;
-        t.y = ws;
-        const double f = (double)p.rem / T;
-        snprintf(nm, sizeof nm, "conv_f32_%s_tail", name);
-        if (int rc = launch_gemm<WM, WN, WAVES_M, WAVES_N, BK, 9, POOL, kTileRaw>(nm, t, p.rem, p.splits, flops * f, bytes * f, s))
-            return rc;
-        char tag[96];
-        snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", a.H, a.Cin, a.Cout);
+        snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", c.H, c.Cin, c.Cout);
         ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
-        conv_fixup_kernel<BM, BN, POOL><<<p.rem, 256, 0, s>>>(ws, a.scale, a.shift, a.y, a.M, a.Cout, a.ntiles, p.whole, p.rem,
-                                                              p.splits, a.alpha);
+        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, 16), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, p.whole,
+                                                                       p.rem, p.splits, c.alpha);
         return ty1::check_launch("conv_fixup");
     }
     return 0;
@@ -729,8 +1110,6 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     const long long mt128 = ((long long)a.M + 127) / 128;
     static const char *force = getenv("TY1_TILE");          // developer override
     if (force && !strcmp(force, "128x128") && Cout % 128 == 0) return run_conv_p<2, 2, 2, 2, 32>("128x128", p, a, ws, ws_bytes, ws_need, s);
-    if (force && !strcmp(force, "w8") && Cout % 128 == 0) return run_conv_p<2, 1, 2, 4, 32>("128x128w8", p, a, ws, ws_bytes, ws_need, s);
-    if (force && !strcmp(force, "w8b") && Cout % 128 == 0) return run_conv_p<1, 2, 4, 2, 32>("128x128w8b", p, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "128x64") && Cout % 64 == 0) return run_conv_p<2, 1, 2, 2, 32>("128x64", p, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "64x64") && Cout % 64 == 0) return run_conv_p<1, 1, 2, 2, 32>("64x64", p, a, ws, ws_bytes, ws_need, s);
     if (Cout % 128 == 0 && mt128 * (Cout / 128) >= 2 * num_cus())
