@@ -45,12 +45,16 @@ def test_model_predict_and_detect_dropin():
     det = ty.TinyYOLOv1(None, None)
     det.model.set_params(prm)
     res = det.detect(x[0].astype(np.float32))
-    want = oracle.decode_nms(y[:1], 2, 20, 448)
+    # bit-exact keep-lists "given identical scores": the scores must come from a forward pass of the same batch
+    # size as detect() uses (the conv kernels pick a K-split per problem size, which changes the f32 summation order)
+    y1 = det.model.predict(x[:1].astype(np.float32), batch_size=1)
+    np.testing.assert_allclose(y1, y[:1], rtol=1e-4, atol=1e-6)
+    want = oracle.decode_nms(y1, 2, 20, 448)
     idx = np.nonzero(want['keep'][0])[0]
     assert np.array_equal(res[0]['slots'], idx)
     assert np.array_equal(res[0]['boxes'].view(np.uint64), want['boxes'][0, idx].view(np.uint64))
     assert res[0]['names'] == [ty.classes_name[c] for c in want['cls'][0, idx]]
-    assert np.array_equal(det.predict(x[0].astype(np.float32)), y[:1])
+    assert np.array_equal(det.predict(x[0].astype(np.float32)), y1)
 
 
 def test_reshape_yolo_call_and_yolo_eval():
@@ -133,14 +137,21 @@ def test_training_step_vs_torch_reference_and_sharded_sum():
     xd, yd = x.to(DEV), torch.from_numpy(y_true).to(DEV)
     feats = model.backbone(xd).cpu().numpy().copy()
     tr = Trainer(model)
-    # (a) sharded gradients summed (what the RCCL all-reduce does) == full-batch gradients
-    tr.gradients(xd, yd)
+    # (a) sharded gradients summed (what the RCCL all-reduce does) == full-batch gradients.  The shards reuse the
+    #     full batch's features: the conv kernels choose a K-split per problem size, so a separately run shard
+    #     differs in the last f32 bits, and yolo_loss' responsible-box mask (iou >= max, yolo/yolo.py:79-82) is
+    #     discontinuous in them; the sum property is a statement about the trainable part of the step.
+    fd = torch.from_numpy(feats).to(DEV)
+    tr.gradients_from_features(fd, yd)
     full_dw, full_db = tr.dwt.clone(), tr.db.clone()
-    la = tr.gradients(xd[:5].contiguous(), yd[:5].contiguous()).clone()
+    la = tr.gradients_from_features(fd[:5].contiguous(), yd[:5].contiguous()).clone()
     dw_a, db_a = tr.dwt.clone(), tr.db.clone()
-    lb = tr.gradients(xd[5:].contiguous(), yd[5:].contiguous()).clone()
+    lb = tr.gradients_from_features(fd[5:].contiguous(), yd[5:].contiguous()).clone()
     torch.testing.assert_close(dw_a + tr.dwt, full_dw, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(db_a + tr.db, full_db, rtol=1e-4, atol=1e-6)
+    # ... and the full path on separately computed shards agrees to forward-pass rounding
+    l5 = tr.gradients(xd[:5].contiguous(), yd[:5].contiguous())
+    assert abs(l5.item() - la.item()) <= 1e-4 * abs(la.item())
     # (b) three optimizer steps against the torch restatement
     losses = [tr.step(xd, yd).item() for _ in range(3)]
     ref_losses, w_ref, b_ref = _torch_train_reference(prm, feats, y_true, 3)

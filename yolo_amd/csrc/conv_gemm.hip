@@ -538,40 +538,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         const int v = full_items + (round - full_rounds) * G + (int)blockIdx.x;
         return v < items ? v : items;
     };
-    int round = 0;
-    Desc cur = decode(item_of(0)), nxt = decode(item_of(1));
-    Rows rc, rn;
-    long long org_c, org_n;
-    make_rows(cur, rc, org_c);
-    make_rows(nxt, rn, org_n);
+    Desc cur = decode(item_of(0)), nxt = decode(items);
+    Rows lr;                                  // rows of the item the fetch cursor is in
+    long long org_l;
+    make_rows(cur, lr, org_l);
 
-    // ---- fetch cursor: two chunks ahead of the MFMAs; crosses from the current item into the next one
+    // ---- fetch cursor: two chunks ahead of the MFMAs.  When it reaches the end of its item it moves on to this
+    //      block's next item (a block-uniform branch taken once per item: new descriptor, new row geometry).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[AP], rb[BP];
-    int ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
-    bool ld_next = false;
+    int ld_round = 0, ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
     auto load_chunk = [&]() {
-        const bool nx = ld_next;
-        const long long org = nx ? org_n : org_c;
-        const long long left = (x_total - org) * 4;
+        const long long left = (x_total - org_l) * 4;
         const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.x + org), 0, (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
+            const_cast<float *>(a.x + org_l), 0, (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
         const int t3 = ld_tap / 3;
         const int dy = t3 - 1, dx = ld_tap - 3 * t3 - 1;
         const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0 + piece * 4) * 4;   // bytes, may be negative
         const unsigned tapbit = 1u << ld_tap;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const unsigned base = nx ? rn.a_base[p] : rc.a_base[p];
-            const unsigned mask = nx ? rn.a_mask[p] : rc.a_mask[p];
-            const unsigned off = (mask & tapbit) ? base + (unsigned)delta : kOOB;
+            const unsigned off = (lr.a_mask[p] & tapbit) ? lr.a_base[p] + (unsigned)delta : kOOB;
             ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
         }
         const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
-            const unsigned bb = nx ? rn.b_base[p] : rc.b_base[p];
-            const unsigned off = bb == kOOB ? kOOB : bb + koff;
+            const unsigned off = lr.b_base[p] == kOOB ? kOOB : lr.b_base[p] + koff;
             rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
         }
         ++ld_kc;
@@ -579,12 +572,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         const bool wrap = ld_ci0 == a.Cin;
         ld_ci0 = wrap ? 0 : ld_ci0;
         ld_tap += wrap ? 1 : 0;
-        const bool cross = ld_kc == ld_end;           // branch-free hop into the next item
-        ld_kc = cross ? nxt.kc0 : ld_kc;
-        ld_end = cross ? nxt.kc1 : ld_end;
-        ld_tap = cross ? nxt.tap0 : ld_tap;
-        ld_ci0 = cross ? nxt.ci0 : ld_ci0;
-        ld_next = ld_next | cross;
+        if (ld_kc == ld_end) {
+            ++ld_round;
+            nxt = decode(item_of(ld_round));
+            make_rows(nxt, lr, org_l);
+            ld_kc = nxt.kc0;
+            ld_end = nxt.kc1;
+            ld_tap = nxt.tap0;
+            ld_ci0 = nxt.ci0;
+        }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -693,49 +689,62 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 
         // ---- epilogue of item `cur`.  Lane holds channel (lane&31) of tile column j; register r is tile row
         //      (r&3) + 8*(r>>2) + 4*(lane>>5).
+        //      Stores go through a buffer resource based at the tile's first output row: one address VGPR per
+        //      tile column, rows past the end of the tensor fall outside the resource and are dropped.
         if (cur.raw) {
-            float *out = a.part + (long long)cur.pslot * (BM * BN);
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                a.part + (long long)cur.pslot * (BM * BN), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int col = wave_n * (32 * WN) + 32 * j + (lane & 31);
+                const unsigned vb = (unsigned)(((wave_m * (32 * WM) + 4 * h) * BN + col) * 4);
 #pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    const int row0 = wave_m * (32 * WM) + 32 * i;
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + col] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];     // (bit_cast straight from the vector element stored element 4*(r/4))
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc,
+                                                              (int)(vb + (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * BN * 4)), 0, 0);
+                    }
             }
         } else {
+            const int rows_out = POOL ? a.M >> 2 : a.M;
+            const int r0 = POOL ? cur.mt * (BM / 4) : cur.mt * BM;
+            const long long obytes = (long long)(rows_out - r0) * a.Cout * 4;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                a.y + (long long)r0 * a.Cout, 0, (int)(obytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : obytes), 0x00020000);
+            const unsigned row_bytes = (unsigned)a.Cout * 4u;
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int n = cur.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
-                if (n < a.Cout) {
+                const bool n_ok = n < a.Cout;
+                if (POOL) {
+                    const unsigned vb = (unsigned)(wave_m * (8 * WM) + h) * row_bytes + (unsigned)n * 4u;
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) {
-                        const int m0 = cur.mt * BM + wave_m * (32 * WM) + 32 * i;
-                        if (POOL) {
+                    for (int i = 0; i < WM; ++i)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                float v[4];
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4];
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    float t = acc[i][j][4 * g + q] * sc[j] + sh[j];
-                                    v[q] = t > 0.f ? t : t * a.alpha;
-                                }
-                                const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                                const int win = (m0 >> 2) + 2 * g + h;
-                                if (win * 4 < a.M) a.y[(long long)win * a.Cout + n] = pooled;
+                            for (int q = 0; q < 4; ++q) {
+                                float t = acc[i][j][4 * g + q] * sc[j] + sh[j];
+                                v[q] = t > 0.f ? t : t * a.alpha;
                             }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                float t = acc[i][j][r] * sc[j] + sh[j];
-                                t = t > 0.f ? t : t * a.alpha;
-                                if (m < a.M) a.y[(long long)m * a.Cout + n] = t;
-                            }
+                            const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                            const unsigned off = n_ok ? vb + (unsigned)(8 * i + 2 * g) * row_bytes : kOOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pooled), o_rsrc, (int)off, 0, 0);
                         }
-                    }
+                } else {
+                    const unsigned vb = (unsigned)(wave_m * (32 * WM) + 4 * h) * row_bytes + (unsigned)n * 4u;
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float t = acc[i][j][r] * sc[j] + sh[j];
+                            t = t > 0.f ? t : t * a.alpha;
+                            const unsigned off = n_ok ? vb + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * row_bytes : kOOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), o_rsrc, (int)off, 0, 0);
+                        }
                 }
             }
         }
@@ -748,14 +757,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         zero_f1();
         if (a.stamp) t2 = __builtin_amdgcn_s_memtime();
 
-        // ---- next item becomes current; the fetch cursor is already inside it
-        ++round;
+        // ---- next item becomes current; the fetch cursor is already two chunks inside it
         cur = nxt;
-        rc = rn;
-        org_c = org_n;
-        ld_next = false;
-        nxt = decode(item_of(round + 1));
-        make_rows(nxt, rn, org_n);
         if (a.stamp) {
             const long long t3 = __builtin_amdgcn_s_memtime();
             t_loop += t1 - t0; t_epi += t2 - t1; t_rows += t3 - t2; ++n_items;

@@ -103,10 +103,13 @@ class Trainer:
 
     def gradients(self, x, y_true):
         """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
+        return self.gradients_from_features(self.model.backbone(x, self.model.workspace(x.shape[0])), y_true)
+
+    def gradients_from_features(self, feats, y_true):
+        """The trainable part of the step (Dense -> head -> yolo_loss and back) on frozen-backbone features (N, K)."""
         m = self.model
-        N = x.shape[0]
+        N = feats.shape[0]
         ws = m.workspace(N)
-        feats = m.backbone(x, ws)
         y = m.head(feats, ws)
         loss, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size)
         dz = self._dz.get(N)
