@@ -31,8 +31,23 @@ def test_version_and_error_channel():
     # argument validation happens before any GPU work: a bad call fails with a message, no crash
     rc = L.ty1_decode_nms(None, 1, 9, 2, 20, 448, 0.2, None, None, None, None, None)
     assert rc != 0 and b'exceeds one wavefront' in L.ty1_last_error()
-    rc = L.ty1_conv3x3_bn_leaky_f32(None, None, None, None, None, 1, 7, 7, 32, 32, 1, 0.1, None)
+    rc = L.ty1_conv3x3_bn_leaky_f32(None, None, None, None, None, 1, 8, 8, 32, 32, 1, 0.1, None)
     assert rc != 0 and b'null pointer' in L.ty1_last_error()
+    rc = L.ty1_conv3x3_bn_leaky_f32(None, None, None, None, None, 1, 7, 7, 32, 32, 1, 0.1, None)
+    assert rc != 0 and b'pool needs even' in L.ty1_last_error()
+
+
+def test_conv_workspace_query_is_host_only():
+    """The K-split plan is pure host arithmetic: sizes for the model's layers at batch 64 (256 CUs assumed
+    when no GPU is visible), 0 where the tile count already divides evenly or for the Cin=3 layer."""
+    L = _lib.lib()
+    n = ctypes.c_size_t(123)
+    assert L.ty1_conv3x3_workspace_bytes(64, 448, 448, 3, 16, 1, ctypes.addressof(n)) == 0 and n.value == 0
+    assert L.ty1_conv3x3_workspace_bytes(64, 224, 224, 16, 32, 1, ctypes.addressof(n)) == 0 and n.value == 0   # 12544 tiles
+    assert L.ty1_conv3x3_workspace_bytes(64, 28, 28, 128, 256, 1, ctypes.addressof(n)) == 0
+    assert 0 < n.value <= 64 << 20 and n.value % (128 * 128 * 4) == 0                                          # 784 tiles of 128x128
+    assert L.ty1_conv3x3_workspace_bytes(64, 7, 7, 1024, 256, 0, ctypes.addressof(n)) == 0 and 0 < n.value <= 64 << 20
+    assert L.ty1_conv3x3_workspace_bytes(64, 7, 7, 1024, 250, 0, ctypes.addressof(n)) != 0                      # Cout % 16
 
 
 def test_fold_bn_host_helper():
