@@ -75,7 +75,8 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
  * /root/reference/models/model_tiny_yolov1.py:89,96.  The bias add and the split-K reduction
  * are fused into ty1_head_activate_f32.
  *   x (N,K) f32 (HWC-flattened features); wt (units, ldk) f32, row u = weights of output unit u;
- *   part (splits, N, ldz) f32 with ldz >= units.  K must be a multiple of 32*splits.
+ *   part (splits, N, ldz) f32 with ldz >= units.  K must be a multiple of 32, splits <= K/32
+ *   (slice s reduces the 32-wide chunks [K/32*s/splits, K/32*(s+1)/splits)).
  */
 int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units,
                          int ldk, int ldz, int splits, ty1_stream_t stream);

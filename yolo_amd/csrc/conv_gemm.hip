@@ -1159,7 +1159,7 @@ extern "C" int ty1_dense_splitk_f32(const float *x, const float *wt, float *part
     TY1_REQUIRE(x && wt && part, "ty1_dense_splitk: null pointer");
     TY1_REQUIRE(ldk >= K && ldk % 4 == 0 && K % 4 == 0, "ty1_dense_splitk: ldk=%d must be >= K=%d, both multiples of 4", ldk, K);
     TY1_REQUIRE(ldz >= units, "ty1_dense_splitk: ldz=%d < units=%d", ldz, units);
-    TY1_REQUIRE(K % (32 * splits) == 0, "ty1_dense_splitk: K=%d must be a multiple of 32*splits (splits=%d)", K, splits);
+    TY1_REQUIRE(K % 32 == 0 && splits <= K / 32, "ty1_dense_splitk: K=%d must be a multiple of 32 and splits=%d at most K/32", K, splits);
     TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wt & 15) == 0, "ty1_dense_splitk: x and wt must be 16-byte aligned");
     ConvArgs a{};
     a.x = x; a.w = wt; a.y = part;

@@ -4,43 +4,57 @@
 //
 // Layouts: Dense output is PLANAR: z[0 : S*S*C] -> (S,S,C), z[S*S*C : +S*S*B] -> (S,S,B),
 // rest -> (S,S,4B); the activated tensor is cell-major (N,S,S,C+5B) = [cls C | conf B | box 4B].
-// One block per image; z is reduced over the split-K partials into LDS once.
+// z is reduced over the split-K partials into LDS once.
 #include "common.h"
 
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// grid (N, ceil(cells / kCellsPerBlock)): a block owns a few cells of one image, so even a small batch
+// spreads over the chip and the split-K reduction (tens of partial slabs) runs as independent loads.
+constexpr int kCellsPerBlock = 7;
+
 __global__ __launch_bounds__(256) void head_activate_kernel(const float *__restrict__ part,
                                                              const float *__restrict__ bias, float *__restrict__ y,
                                                              int N, int S, int B, int C, int ldz, int splits) {
-    extern __shared__ float z[];
+    extern __shared__ float z[];                       // [cells_here][D]  cell-major, already in the output layout
     const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
-    for (int u = threadIdx.x; u < units; u += blockDim.x) {
-        float acc = bias ? bias[u] : 0.f;
-        for (int s = 0; s < splits; ++s) acc += part[((size_t)s * N + n) * ldz + u];
-        z[u] = acc;
+    const int c0 = blockIdx.y * kCellsPerBlock, nc = min(kCellsPerBlock, cells - c0);
+    const int i1 = cells * C, i2 = i1 + cells * B;
+    const size_t slab = (size_t)N * ldz;
+    const float *pn = part + (size_t)n * ldz;
+    for (int t = threadIdx.x; t < nc * D; t += blockDim.x) {
+        const int lc = t / D, d = t - lc * D, cell = c0 + lc;
+        // planar Dense unit of (cell, channel d)
+        const int u = d < C ? cell * C + d : (d < C + B ? i1 + cell * B + (d - C) : i2 + cell * 4 * B + (d - C - B));
+        float a0 = bias ? bias[u] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            a0 += pn[(size_t)s * slab + u];
+            a1 += pn[(size_t)(s + 1) * slab + u];
+            a2 += pn[(size_t)(s + 2) * slab + u];
+            a3 += pn[(size_t)(s + 3) * slab + u];
+        }
+        for (; s < splits; ++s) a0 += pn[(size_t)s * slab + u];
+        z[t] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    float *out = y + (size_t)n * units;
-    const int i1 = cells * C, i2 = i1 + cells * B;
-    // softmax over the C classes of one cell: one thread per cell
-    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
-        const float *zc = z + cell * C;
-        float mx = zc[0];
-        for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
-        float sum = 0.f;
-        for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
-        const float inv = 1.0f / sum;
-        for (int m = 0; m < C; ++m) out[cell * D + m] = expf(zc[m] - mx) * inv;
-    }
-    for (int i = threadIdx.x; i < cells * B; i += blockDim.x) {
-        const int cell = i / B, k = i - cell * B;
-        out[cell * D + C + k] = sigmoidf_(z[i1 + i]);
-    }
-    for (int i = threadIdx.x; i < cells * 4 * B; i += blockDim.x) {
-        const int cell = i / (4 * B), k = i - cell * (4 * B);
-        out[cell * D + C + B + k] = sigmoidf_(z[i2 + i]);
+    float *out = y + (size_t)n * units + (size_t)c0 * D;
+    for (int t = threadIdx.x; t < nc * D; t += blockDim.x) {
+        const int lc = t / D, d = t - lc * D;
+        const float *zc = z + lc * D;
+        float r;
+        if (d < C) {                                   // softmax over the C classes of the cell
+            float mx = zc[0];
+            for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
+            float sum = 0.f;
+            for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
+            r = expf(zc[d] - mx) / sum;
+        } else {
+            r = sigmoidf_(zc[d]);
+        }
+        out[t] = r;
     }
 }
 
@@ -78,10 +92,12 @@ extern "C" int ty1_head_activate_f32(const float *part, const float *bias, float
     const int units = S * S * (C + 5 * B);
     TY1_REQUIRE(part && y, "ty1_head_activate: null pointer");
     TY1_REQUIRE(ldz >= units, "ty1_head_activate: ldz=%d < units=%d", ldz, units);
-    TY1_REQUIRE((size_t)units * 4 <= 64 * 1024, "ty1_head_activate: %d units exceed the LDS budget", units);
+    const int D = C + 5 * B;
+    TY1_REQUIRE((size_t)kCellsPerBlock * D * 4 <= 64 * 1024, "ty1_head_activate: %d channels per cell exceed the LDS budget", D);
     hipStream_t s = (hipStream_t)stream;
-    ty1::ProfScope prof("head_activate", s);
-    head_activate_kernel<<<dim3(N), dim3(256), (size_t)units * 4, s>>>(part, bias, y, N, S, B, C, ldz, splits);
+    ty1::ProfScope prof("head_activate", s, 0.0, 4.0 * N * units * (splits + 1.0));
+    head_activate_kernel<<<dim3(N, (S * S + kCellsPerBlock - 1) / kCellsPerBlock), dim3(256), (size_t)kCellsPerBlock * D * 4, s>>>(
+        part, bias, y, N, S, B, C, ldz, splits);
     return ty1::check_launch("ty1_head_activate_f32");
 }
 

@@ -66,14 +66,19 @@ def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None, workspa
     return out
 
 
-def pick_splits(K, n_rows, units):
-    """Split-K factor for the Dense GEMM: enough blocks to fill 256 CUs, K/32 divisible."""
+def pick_splits(K, n_rows, units, slots=512):
+    """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills whole rounds of
+    `slots` resident blocks (2 per CU), with at least 4 chunks of 32 per slice."""
     chunks = K // DENSE_K_ALIGN
     tiles = ((n_rows + 63) // 64) * ((units + 63) // 64) if n_rows > 32 else (units + 127) // 128
-    best = 1
-    for s in range(1, chunks + 1):
-        if chunks % s == 0 and tiles * s <= 1024:
-            best = s
+    best, best_eff = 1, 0.0
+    for s in range(1, max(1, chunks // 4) + 1):
+        blocks = tiles * s
+        if blocks > 2 * slots:
+            break
+        eff = blocks / (-(-blocks // slots) * slots)
+        if eff > best_eff + 1e-9:
+            best, best_eff = s, eff
     return best
 
 
