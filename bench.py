@@ -26,22 +26,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: den
 PEAK_HBM_GBS = 8000.0
 
 # libty1 event-timer name -> kernel symbol as rocprofv3 --kernel-trace prints it
-ROCPROF_SYMBOL = {
-    'conv_f32_128x128_pool': 'conv_gemm_f32_kernel<2, 2, 2, 2, 32, 9, true, false>',
-    'conv_f32_128x128': 'conv_gemm_f32_kernel<2, 2, 2, 2, 32, 9, false, false>',
-    'conv_f32_128x64_pool': 'conv_gemm_f32_kernel<2, 1, 2, 2, 32, 9, true, false>',
-    'conv_f32_128x64': 'conv_gemm_f32_kernel<2, 1, 2, 2, 32, 9, false, false>',
-    'conv_f32_64x64_pool': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 9, true, false>',
-    'conv_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 9, false, false>',
-    'conv_f32_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 32, 9, true, false>',
-    'conv_f32_bk16_256x32_pool': 'conv_gemm_f32_kernel<2, 1, 4, 1, 16, 9, true, false>',
-    'conv_f32_bk16_128x64_pool': 'conv_gemm_f32_kernel<2, 1, 2, 2, 16, 9, true, false>',
-    'conv3x3_c3_pool': 'conv3x3_c3_kernel<true, 1>',
-    'dense_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 1, false, true>',
-    'dense_f32_32x128': 'conv_gemm_f32_kernel<1, 1, 1, 4, 32, 1, false, true>',
-    'decode_nms': 'decode_nms_kernel<2>',
-    'head_activate': 'head_activate_kernel',
-}
+_CFG = {'128x128': '2, 2, 2, 2, 32', '128x64': '2, 1, 2, 2, 32', '64x64': '1, 1, 2, 2, 32', '256x32': '2, 1, 4, 1, 32',
+        'bk16_128x64': '2, 1, 2, 2, 16', 'bk16_256x32': '2, 1, 4, 1, 16'}
+ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3_kernel<true, 1>',
+                  'dense_f32_64x64': 'conv_gemm_f32_kernel<1, 1, 2, 2, 32, 1, false, 1>',
+                  'dense_f32_32x128': 'conv_gemm_f32_kernel<1, 1, 1, 4, 32, 1, false, 1>',
+                  'decode_nms': 'decode_nms_kernel<2>', 'head_activate': 'head_activate_kernel'}
+for _k, _v in _CFG.items():
+    ROCPROF_SYMBOL[f'conv_f32_{_k}_pool'] = f'conv_persist_kernel<{_v}, true>'
+    ROCPROF_SYMBOL[f'conv_f32_{_k}'] = f'conv_persist_kernel<{_v}, false>'
 
 
 def cpu_baseline(prm, x_cpu, n_images, C=20):

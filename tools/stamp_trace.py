@@ -39,6 +39,16 @@ if args.persist:
     print(f'per item (shader cycles): loop {np.mean(b[:, 1] / ni):.0f}  epilogue {np.mean(b[:, 2] / ni):.0f}  rows {np.mean(b[:, 6] / ni):.0f}'
           f'   block time {np.mean(end - st):.1f} us -> {np.mean((end - st) / ni):.2f} us per item')
     print('end-time histogram:', np.histogram(end, bins=8)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
+    hw = b[:, 4]; xcc = b[:, 5] & 0xF
+    cuid = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)
+    ids = np.nonzero(ball[:cap // 2, 0] != 0)[0]
+    groups = {}
+    for bi, c in zip(ids, cuid):
+        groups.setdefault(int(c), []).append(int(bi))
+    diffs = [g[1] - g[0] for g in groups.values() if len(g) == 2]
+    print('CUs', len(groups), 'blocks per CU', np.bincount([len(g) for g in groups.values()]).tolist(),
+          'index distance of CU partners:', dict(zip(*[x.tolist() for x in np.unique(diffs, return_counts=True)])))
+    print('xcc of blocks 0..15:', xcc[:16].tolist())
     sys.exit(0)
 st, pro, loop, end = ((b[:, i] - t0) / 100.0 for i in range(4))     # microseconds
 hw = b[:, 4]

@@ -428,7 +428,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int NTHREADS = 256;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    constexpr int LDS_STRIDE = BK + 4;
+    // LDS tiles are [row][BK] with NO padding; the 16-byte slot of a row is XOR-swizzled with the row's index in
+    // its 256-byte bank row group, which makes the ds_read_b128 16-lane groups and the 8-lane store groups
+    // conflict-free (the padded layout costs 12 % more LDS: 128x64 tiles then fit three workgroups per CU).
+    constexpr int LDS_STRIDE = BK;
+    constexpr int RB = 64 / BK;               // rows per 256-byte LDS bank row
     constexpr int CPR = BK / 4, RPP = NTHREADS / CPR;
     constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
     constexpr int NKB = BK / 8;
@@ -583,14 +587,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         }
     };
     auto store_chunk = [&](int buf) {
+        // RPP is a multiple of RB * CPR, so the swizzle of row p * RPP + prow does not depend on p
+        const int sp = (piece ^ ((prow / RB) & (CPR - 1))) * 4;
 #pragma unroll
         for (int p = 0; p < AP; ++p)
             if (AP * RPP == BM || p * RPP + prow < BM)
-                *reinterpret_cast<u32x4 *>(&As[buf][(p * RPP + prow) * LDS_STRIDE + piece * 4]) = ra[p];
+                *reinterpret_cast<u32x4 *>(&As[buf][(p * RPP + prow) * LDS_STRIDE + sp]) = ra[p];
 #pragma unroll
         for (int p = 0; p < BP; ++p)
             if (BP * RPP == BN || p * RPP + prow < BN)
-                *reinterpret_cast<u32x4 *>(&Bs[buf][(p * RPP + prow) * LDS_STRIDE + piece * 4]) = rb[p];
+                *reinterpret_cast<u32x4 *>(&Bs[buf][(p * RPP + prow) * LDS_STRIDE + sp]) = rb[p];
     };
 
     f32x16 acc[WM][WN];
@@ -601,9 +607,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
+    static_assert(RPP % (RB * CPR) == 0 && 32 % (RB * CPR) == 0, "row swizzle is periodic in the fetch pass and the MFMA tile");
+    const int frag_row = lane & 31, frag_h = lane >> 5;
     const int a_row0 = wave_m * (32 * WM) + frag_row;
     const int b_row0 = wave_n * (32 * WN) + frag_row;
+    const int a_swz = (a_row0 / RB) & (CPR - 1), b_swz = (b_row0 / RB) & (CPR - 1);
     struct Frag {
         float a[WM][4], b[WN][4];
     };
@@ -611,13 +619,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const float4 v = *reinterpret_cast<const float4 *>(
-                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k], 16));
+                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + (((kb * 2 + frag_h) ^ a_swz) << 2)], 16));
             f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const float4 v = *reinterpret_cast<const float4 *>(
-                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k], 16));
+                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + (((kb * 2 + frag_h) ^ b_swz) << 2)], 16));
             f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
         }
     };
@@ -1039,7 +1047,17 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     a.whole = p.whole; a.rem = p.rem; a.splits = p.splits;
     a.d_splits = make_fastdiv(p.splits);
     const int items = p.whole + p.rem * p.splits;
-    const int grid = items < 2 * num_cus() ? items : 2 * num_cus();
+    // persistent grid: as many workgroups as stay resident together (LDS / register limited), at least 2 per CU
+    static const int occ = [] {
+        int n = 0;
+        static const char *cap = getenv("TY1_MAX_BLOCKS_PER_CU");
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL>,
+                                                         64 * WAVES_M * WAVES_N, 0) != hipSuccess || n < 1)
+            n = 2;
+        if (cap && atoi(cap) > 0 && n > atoi(cap)) n = atoi(cap);
+        return n > 4 ? 4 : n;
+    }();
+    const int grid = items < occ * num_cus() ? items : occ * num_cus();
     a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
     const double K = 9.0 * c.Cin, out_rows = POOL ? c.M / 4.0 : (double)c.M;
