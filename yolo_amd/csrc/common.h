@@ -31,6 +31,10 @@ inline int check_launch(const char *what) {
     return 0;
 }
 
+// conv_direct.hip
+int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
+                       int W, int Cout, int pool, float alpha, hipStream_t s);
+
 }  // namespace ty1
 
 #define TY1_REQUIRE(cond, ...)                       \

@@ -1,0 +1,204 @@
+// Direct 3x3 convolution for a shallow input (Cin = 16: the second block of the backbone, K = 144), fused with
+// folded BatchNorm + LeakyReLU + 2x2/2 max-pool, on v_mfma_f32_32x32x2_f32.
+// Replaces /root/reference/models/model_tiny_yolov1.py:49-53 (convolution_1 block) for Cin = 16, Cout = 32 or 64.
+//
+// With K = 144 the implicit-GEMM pipeline (conv_gemm.hip) spends its time on per-tile overhead: a tile is nine short
+// chunks.  Here the reduction is not tiled at all:
+//   - the weights of the wave's 32 output channels live in REGISTERS for the whole kernel: MFMA B operand
+//     B[k][col] with k = (tap, ci); lane (col = lane&31, h = lane>>5) holds w[col][tap][8g + 4h + j] (72 VGPRs per
+//     32 channels), read once per workgroup;
+//   - a persistent workgroup walks 8 x 32 pixel patches; the 10 x 34 pixel halo of the NEXT patch is fetched into
+//     registers while the current one multiplies and stored to the other LDS buffer afterwards (coalesced 64-byte pixels),
+//     pixel stride 20 floats and row stride = 32 mod 64 floats, which makes every ds_read_b128 of an A fragment
+//     conflict-free for the 2-row x 16-column MFMA tile used below;
+//   - an MFMA tile is 32 pixels = 8 pool windows (2 rows x 16 columns), rows ordered m = 4*window + (dy*2+dx), so the
+//     four pixels of a window are the four consecutive accumulator registers of a lane (C/D row = (r&3) + 8(r>>2) +
+//     4(lane>>5)) and the max-pool is three v_max in registers;
+//   - one ds_read_b128 feeds four MFMAs (ci = 8g + 4h + j, j = 0..3); a wave owns 2 rows x 32 columns = two tiles.
+// Two workgroups (2 x 29.4 KB of LDS each) share a CU.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 32;              // patch of pre-pool pixels per pipeline step
+constexpr int CS = 20;                      // LDS floats per pixel (16 channels + 4 pad)
+constexpr int RS = 736;                     // LDS floats per patch row: >= (TW+2)*CS = 680 and = 32 (mod 64)
+constexpr int CIN = 16;
+constexpr int STAGE_ITEMS = (TH + 2) * (TW + 2) * 4;            // 16-byte pieces of one halo
+constexpr int STAGE_PER_THREAD = (STAGE_ITEMS + 255) / 256;     // 6
+
+template <bool POOL, int NT>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          float *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
+                                                          int tiles_x, int tiles_y, int patches) {
+    __shared__ __attribute__((aligned(16))) float tile[2][(TH + 2) * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+
+    // ---- weights of this lane: wreg[nt][tap][g] = w[32nt + col][tap][8g + 4h .. +3]   (OHWI, 16 floats per tap)
+    float4 wreg[NT][9][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                wreg[nt][t][g] = *reinterpret_cast<const float4 *>(w + ((size_t)(32 * nt + col) * 9 + t) * CIN + 8 * g + 4 * h);
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        sc[nt] = scale[32 * nt + col];
+        sh[nt] = shift[32 * nt + col];
+    }
+
+    // ---- halo staging through registers: fetch patch p+1 while patch p multiplies, store it after the MFMAs
+    //      rows y0-1 .. y0+TH, pixels x0-1 .. x0+TW, 4 x 16-byte pieces per pixel, zero outside the image
+    float4 stage[STAGE_PER_THREAD];
+    int lds_off[STAGE_PER_THREAD], st_rr[STAGE_PER_THREAD], st_pp[STAGE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < STAGE_PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        const int piece = i & 3, pix = i >> 2;
+        st_rr[k] = pix / (TW + 2);
+        st_pp[k] = pix - st_rr[k] * (TW + 2);
+        lds_off[k] = i < STAGE_ITEMS ? st_rr[k] * RS + st_pp[k] * CS + piece * 4 : -1;
+    }
+    auto decode = [&](int p, int &n, int &y0, int &x0) {
+        const int tx = p % tiles_x;
+        const int r = p / tiles_x;
+        const int ty = r % tiles_y;
+        n = r / tiles_y;
+        y0 = ty * TH;
+        x0 = tx * TW;
+    };
+    auto fetch = [&](int p) {
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+        const bool live = p < patches;
+        const float *img = x + (size_t)n * H * W * CIN;
+#pragma unroll
+        for (int k = 0; k < STAGE_PER_THREAD; ++k) {
+            const int yy = y0 - 1 + st_rr[k], xx = x0 - 1 + st_pp[k];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && lds_off[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = *reinterpret_cast<const float4 *>(img + ((size_t)yy * W + xx) * CIN + ((tid + 256 * k) & 3) * 4);
+            stage[k] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < STAGE_PER_THREAD; ++k)
+            if (lds_off[k] >= 0) *reinterpret_cast<float4 *>(&tile[buf][lds_off[k]]) = stage[k];
+    };
+
+    // ---- this lane's pixel inside an MFMA tile: window wdw = (lane&31)>>2 of 8 along x, q = lane&3 inside the window
+    const int q = lane & 3, wdw = (lane & 31) >> 2;
+    const int lane_off = (q >> 1) * RS + (2 * wdw + (q & 1)) * CS + 4 * h;    // + tile origin + tap offset + 8g
+    const int prow = 2 * wave;                               // wave owns pixel rows 2*wave, 2*wave+1 of the patch
+    const int base0 = prow * RS + lane_off, base1 = base0 + 16 * CS;          // tile columns 0 and 1 (16 pixels apart)
+
+    int p = blockIdx.x;
+    fetch(p);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (; p < patches; p += gridDim.x) {
+        fetch(p + gridDim.x);                               // lands during the MFMAs below (nothing past the end)
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
+        const float *tl = tile[buf];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * RS + (t % 3) * CS;   // halo origin is (y0-1, x0-1): tap (dy,dx) = (t/3-1, t%3-1)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(&tl[base0 + toff + 8 * g]);
+                const float4 a1 = *reinterpret_cast<const float4 *>(&tl[base1 + toff + 8 * g]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 wv = wreg[nt][t][g];
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wv.x, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wv.x, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wv.y, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wv.y, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wv.z, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wv.z, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wv.w, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wv.w, acc[1][nt], 0, 0, 0);
+                }
+            }
+        }
+        store(buf ^ 1);                                     // that buffer was last read before the previous barrier
+        // ---- epilogue: register group gq = r>>2 with lane half h is window 2*gq + h of the tile; r&3 = position in it
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = 32 * nt + col;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[u][nt][4 * gq + r] * sc[nt] + sh[nt];
+                        v[r] = z > 0.f ? z : z * alpha;
+                    }
+                    const int wx = 8 * u + 2 * gq + h;                      // window column inside the patch row pair
+                    if (POOL) {
+                        const int oy = (y0 + prow) >> 1, ox = (x0 >> 1) + wx;
+                        if (oy < (H >> 1) && ox < (W >> 1))
+                            y[(((size_t)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int oy = y0 + prow + (r >> 1), ox = x0 + 2 * wx + (r & 1);
+                            if (oy < H && ox < W) y[(((size_t)n * H + oy) * W + ox) * Cout + co] = v[r];
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+}  // namespace
+
+namespace ty1 {
+
+// Cin == 16, Cout == 32 or 64.  Returns 0 on success (error text via ty1::fail).
+int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
+                       int W, int Cout, int pool, float alpha, hipStream_t s) {
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long long patches = (long long)N * tiles_y * tiles_x;
+    TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c16): too many patches");
+    const double px = (double)N * H * W;
+    ProfScope prof(pool ? "conv3x3_c16_pool" : "conv3x3_c16", s, 2.0 * px * Cout * 144,
+                   4.0 * (px * 16 + 144.0 * Cout + px * Cout / (pool ? 4 : 1)));
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    const long long want = 2ll * cus;                        // persistent: two workgroups (59 KB of LDS each) per CU
+    dim3 grid((unsigned)(patches < want ? patches : want)), block(256);
+    const int P = (int)patches;
+    if (Cout == 32) {
+        if (pool) conv3x3_c16_kernel<true, 1><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+        else conv3x3_c16_kernel<false, 1><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+    } else {
+        if (pool) conv3x3_c16_kernel<true, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+        else conv3x3_c16_kernel<false, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+    }
+    return check_launch("ty1_conv3x3(c16)");
+}
+
+}  // namespace ty1

@@ -414,12 +414,17 @@ struct PersistArgs {
     int NB, H, W, Cin, Cout, M;
     int chunks_total;
     float alpha;
-    int ntiles;          // tiles along N
+    int ntiles, mtiles;  // tiles along N and M
+    // Tile order.  An XCD walks a contiguous range of logical tiles, so the fast index should be the one whose
+    // operand panel is re-fetched: with a small weight matrix nt runs fastest (the A tile is shared by the
+    // neighbours); when the weights do not fit the 4 MiB L2 next to the activations, mt runs fastest so that an
+    // XCD keeps one or two weight panels resident and streams the (small) activation tensor instead.
+    int mt_fastest;
     // work items: logical tiles [0, whole) with the fused epilogue, then the last `rem` tiles cut into `splits`
     // K pieces each (item whole + j: tile whole + j / splits, piece j % splits) that store raw partial tiles
     int whole, rem, splits;
     FastDiv d_img, d_row;   // pooled layers: (H/2)*(W/2), W/2; otherwise H*W, W
-    FastDiv d_splits, d_ntiles, d_cpt;   // splits, ntiles, chunks per tap
+    FastDiv d_splits, d_ntiles, d_mtiles, d_cpt;   // splits, ntiles, mtiles, chunks per tap
     long long *stamp;
 };
 
@@ -471,8 +476,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         const int tail_tile = (int)fdiv((unsigned)j, a.d_splits);
         const int split = j - tail_tile * a.splits;
         const int logical = d.raw ? a.whole + tail_tile : (d.live ? it : 0);
-        d.mt = (int)fdiv((unsigned)logical, a.d_ntiles);
-        d.nt = logical - d.mt * a.ntiles;
+        if (a.mt_fastest) {                       // logical = nt * mtiles + mt
+            d.nt = (int)fdiv((unsigned)logical, a.d_mtiles);
+            d.mt = logical - d.nt * a.mtiles;
+        } else {                                  // logical = mt * ntiles + nt
+            d.mt = (int)fdiv((unsigned)logical, a.d_ntiles);
+            d.nt = logical - d.mt * a.ntiles;
+        }
         d.kc0 = d.raw ? a.chunks_total * split / a.splits : 0;
         d.kc1 = d.raw ? a.chunks_total * (split + 1) / a.splits : (d.live ? a.chunks_total : 0x7fffffff);
         d.tap0 = (int)fdiv((unsigned)d.kc0, a.d_cpt);
@@ -787,11 +797,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 template <int BM, int BN, bool POOL>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict__ part, const float *__restrict__ scale,
                                                          const float *__restrict__ shift, float *__restrict__ y,
-                                                         int M, int Cout, int ntiles, int tile_begin, int tiles,
-                                                         int splits, float alpha) {
+                                                         int M, int Cout, int ntiles, int mtiles, int mt_fastest,
+                                                         int tile_begin, int tiles, int splits, float alpha) {
     const int tile_local = blockIdx.x;
     const int logical = tile_begin + tile_local;
-    const int mt = logical / ntiles, nt = logical - mt * ntiles;
+    const int mt = mt_fastest ? logical % mtiles : logical / ntiles;
+    const int nt = mt_fastest ? logical / mtiles : logical % ntiles;
     constexpr int ROWS = POOL ? BM / 4 : BM, C4 = BN / 4;
     const long long split_stride = (long long)tiles * BM * BN;
     const float *base = part + (long long)tile_local * BM * BN;
@@ -1035,6 +1046,9 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     a.d_img = make_fastdiv(POOL ? (c.H / 2) * (c.W / 2) : c.H * c.W);
     a.d_row = make_fastdiv(POOL ? c.W / 2 : c.W);
     a.d_ntiles = make_fastdiv(a.ntiles);
+    a.mtiles = (c.M + BM - 1) / BM;
+    a.d_mtiles = make_fastdiv(a.mtiles);
+    a.mt_fastest = (9.0 * c.Cin * c.Cout * 4 > 2.0 * 1024 * 1024) ? 1 : 0;
     a.d_cpt = make_fastdiv(c.Cin / BK);
     const int T = ((c.M + BM - 1) / BM) * a.ntiles;
     TailPlan p = plan_tail(T, a.chunks_total, num_cus());
@@ -1071,7 +1085,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     if (p.rem) {
         snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", c.H, c.Cin, c.Cout);
         ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
-        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, 16), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, p.whole,
+        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, 16), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
                                                                        p.rem, p.splits, c.alpha);
         return ty1::check_launch("conv_fixup");
     }
@@ -1122,6 +1136,11 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     a.alpha = alpha;
     const bool p = pool != 0;
 
+    static const char *no_direct = getenv("TY1_NO_DIRECT16");          // developer override
+    if (Cin == 16 && (Cout == 32 || Cout == 64) && !no_direct) {       // shallow K: direct kernel, weights in registers
+        if (ws_need) return 0;
+        return ty1::conv3x3_c16_direct(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
+    }
     // tile choice: keep BN <= Cout; big tiles once they fill the chip, 64x64 for the 7x7 layers
     if (Cin % 32 != 0) {              // Cin == 16 (48, 80 ...): BK = 16
         if (Cout % 64 == 0) return run_conv_p<2, 1, 2, 2, 16>("bk16_128x64", p, a, ws, ws_bytes, ws_need, s);
