@@ -159,6 +159,17 @@ def main():
                           'share': round(v['ms'] / gpu_ms, 3)}
         conv_flops = sum(v['flops'] for k, v in table.items() if k.startswith(('conv', 'dense')))
         conv_ms = sum(v['ms'] for k, v in table.items() if k.startswith(('conv', 'dense')))
+        # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
+        # (tools/profile.sh), committed under profiles/; averaged over that symbol's launches in one step
+        traffic, traffic_src = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            sym = (ROCPROF_SYMBOL.get(dom_name) or '').replace('(anonymous namespace)::', '')
+            if sym in pj['kernels']:
+                traffic = round(pj['kernels'][sym]['hbm_read_bytes'] + pj['kernels'][sym]['hbm_write_bytes'])
+                traffic_src = pj['source']
+        except Exception:
+            pass
         out = {
             'metric': 'images/sec tiny-YOLOv1 448x448 inference incl. decode+NMS',
             'value': round(world * N * args.steps / elapsed, 1),
@@ -176,7 +187,7 @@ def main():
                        'kept_boxes_per_image': round(kept_per_image, 2)},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'rocprof_symbol': ROCPROF_SYMBOL.get(dom_name),
                          'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
                          'launches': dom['launches'], 'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
                          'algo_flops_per_launch': dom['flops'] / dom['launches'],
                          'all_matmul_kernels_tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),

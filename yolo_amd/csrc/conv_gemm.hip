@@ -415,10 +415,9 @@ struct PersistArgs {
     int chunks_total;
     float alpha;
     int ntiles, mtiles;  // tiles along N and M
-    // Tile order.  An XCD walks a contiguous range of logical tiles, so the fast index should be the one whose
-    // operand panel is re-fetched: with a small weight matrix nt runs fastest (the A tile is shared by the
-    // neighbours); when the weights do not fit the 4 MiB L2 next to the activations, mt runs fastest so that an
-    // XCD keeps one or two weight panels resident and streams the (small) activation tensor instead.
+    // Tile order.  An XCD walks a contiguous range of logical tiles and its resident tiles stream K in step, so
+    // tiles that share an operand panel should be neighbours: nt fastest = the tiles of one A panel side by side
+    // (each B panel is then shared by resident/ntiles of them).  mt fastest is kept as an option only.
     int mt_fastest;
     // work items: logical tiles [0, whole) with the fused epilogue, then the last `rem` tiles cut into `splits`
     // K pieces each (item whole + j: tile whole + j / splits, piece j % splits) that store raw partial tiles
@@ -1048,7 +1047,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     a.d_ntiles = make_fastdiv(a.ntiles);
     a.mtiles = (c.M + BM - 1) / BM;
     a.d_mtiles = make_fastdiv(a.mtiles);
-    a.mt_fastest = (9.0 * c.Cin * c.Cout * 4 > 2.0 * 1024 * 1024) ? 1 : 0;
+    a.mt_fastest = 0;     // measured (rocprofv3 FETCH_SIZE, batch 64): mt-fastest raised L2 misses 1.5-5x on the deep layers
     a.d_cpt = make_fastdiv(c.Cin / BK);
     const int T = ((c.M + BM - 1) / BM) * a.ntiles;
     TailPlan p = plan_tail(T, a.chunks_total, num_cus());
