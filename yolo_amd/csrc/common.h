@@ -32,6 +32,8 @@ inline int check_launch(const char *what) {
 }
 
 // conv_direct.hip
+int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
+                          int W, int Cout, int pool, float alpha, hipStream_t s);
 int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
                        int W, int Cout, int pool, float alpha, hipStream_t s);
 

@@ -172,6 +172,163 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// First layer (Cin = 3, K = 27 -> 28) as a persistent kernel on v_mfma_f32_16x16x4_f32: same arithmetic as
+// conv3x3_c3_kernel (conv_gemm.hip: halo tile in LDS, 7 weight registers per 16 channels, one pool window per
+// lane), but a workgroup walks 16 x 64 pixel patches, fetches the NEXT patch's halo with 16-byte loads into
+// registers while the current patch multiplies, and stores it to the other LDS buffer afterwards.  The layer is
+// bound by its 406 MB of HBM traffic at batch 64, so what matters is that loads are wide and always in flight.
+// Needs W % 4 == 0 and a 16-byte aligned input (an image row is then a whole number of float4).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int C3_TH = 16, C3_TW = 64;
+constexpr int C3_ROW = 208;                                  // LDS floats per halo row (200 used); 208 % 32 == 16
+constexpr int C3_V4 = 50;                                    // float4 per halo row: floats 3*x0 - 4 .. 3*x0 + 195
+constexpr int C3_ITEMS = (C3_TH + 2) * C3_V4;                // 900
+constexpr int C3_PER_THREAD = (C3_ITEMS + 255) / 256;        // 4
+
+template <bool POOL, int NT>
+__global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          float *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
+                                                          int tiles_x, int tiles_y, int patches) {
+    __shared__ __attribute__((aligned(16))) float tile[2][(C3_TH + 2) * C3_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+
+    // weights of this lane: B[k = 4*ks + kq][channel 16*j + i16]; k = 27 is the zero pad
+    float wreg[NT][7];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int k = 4 * ks + kq;
+            wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] : 0.f;
+        }
+    // A-operand LDS offset of this lane for every k step, relative to the pixel's top-left tap
+    int koff[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int k = 4 * ks + kq;
+        const int kh = k / 9;
+        koff[ks] = k < 27 ? kh * C3_ROW + (k - 9 * kh) : 0;  // k = 27: any valid address (weight is 0)
+    }
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        sc[j] = scale[16 * j + i16];
+        sh[j] = shift[16 * j + i16];
+    }
+
+    float4 stage[C3_PER_THREAD];
+    int st_rr[C3_PER_THREAD], st_c[C3_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < C3_PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        st_rr[k] = i < C3_ITEMS ? i / C3_V4 : -1;
+        st_c[k] = i - (i / C3_V4) * C3_V4;
+    }
+    auto decode = [&](int p, int &n, int &y0, int &x0) {
+        const int tx = p % tiles_x;
+        const int r = p / tiles_x;
+        const int ty = r % tiles_y;
+        n = r / tiles_y;
+        y0 = ty * C3_TH;
+        x0 = tx * C3_TW;
+    };
+    const int row_f = 3 * W;                                 // floats per image row
+    auto fetch = [&](int p) {
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+        const bool live = p < patches;
+        const float *img = x + (size_t)n * H * row_f;
+#pragma unroll
+        for (int k = 0; k < C3_PER_THREAD; ++k) {
+            const int yy = y0 - 1 + st_rr[k], g0 = 3 * x0 - 4 + 4 * st_c[k];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live && st_rr[k] >= 0 && yy >= 0 && yy < H && g0 >= 0 && g0 + 3 < row_f)
+                v = *reinterpret_cast<const float4 *>(img + (size_t)yy * row_f + g0);
+            stage[k] = v;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < C3_PER_THREAD; ++k)
+            if (st_rr[k] >= 0) *reinterpret_cast<float4 *>(&tile[buf][st_rr[k] * C3_ROW + 4 * st_c[k]]) = stage[k];
+    };
+
+    // pixel of this lane inside an M-tile: window (i16>>2) of 4, position q = i16&3 in the 2x2 window
+    const int q = i16 & 3;
+    const int lane_px = 2 * (i16 >> 2) + (q & 1), lane_py = q >> 1;
+
+    int p = blockIdx.x;
+    fetch(p);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (; p < patches; p += gridDim.x) {
+        fetch(p + gridDim.x);                                // in flight during the MFMAs (nothing past the end)
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+        const float *tl = tile[buf];
+        for (int t2 = 0; t2 < 16; t2 += 2) {                 // two M-tiles per iteration (independent chains)
+            f32x4 acc[2][NT];
+            int base[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = t2 + u;
+                const int pr = t >> 3, wcol = (t & 7) * 4;   // pooled row in the wave's strip, first window
+                const int py = 4 * wave + 2 * pr + lane_py, px = 2 * wcol + lane_px;
+                base[u] = py * C3_ROW + px * 3 + 1;          // halo float 0 is image float 3*x0 - 4: pixel x0-1 starts at 1
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const float a0 = tl[base[0] + koff[ks]];
+                const float a1 = tl[base[1] + koff[ks]];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[j][ks], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[j][ks], acc[1][j], 0, 0, 0);
+                }
+            }
+            // epilogue: this lane holds pool window (wcol + kq) of pooled row pr, channel 16j + i16
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = t2 + u;
+                const int pr = t >> 3, win = (t & 7) * 4 + kq;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int co = 16 * j + i16;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[u][j][r] * sc[j] + sh[j];
+                        v[r] = z > 0.f ? z : z * alpha;
+                    }
+                    if (POOL) {
+                        const int oy = (y0 >> 1) + 2 * wave + pr, ox = (x0 >> 1) + win;
+                        if (oy < (H >> 1) && ox < (W >> 1))
+                            y[(((size_t)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int oy = y0 + 4 * wave + 2 * pr + (r >> 1), ox = x0 + 2 * win + (r & 1);
+                            if (oy < H && ox < W) y[(((size_t)n * H + oy) * W + ox) * Cout + co] = v[r];
+                        }
+                    }
+                }
+            }
+        }
+        store(buf ^ 1);                                      // that buffer was last read before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 }  // namespace
 
 namespace ty1 {
@@ -199,6 +356,29 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
         else conv3x3_c16_kernel<false, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
     }
     return check_launch("ty1_conv3x3(c16)");
+}
+
+
+// Cin == 3, Cout == 16 * NT (NT <= 4), W % 4 == 0, x 16-byte aligned.
+int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
+                          int W, int Cout, int pool, float alpha, hipStream_t s) {
+    const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
+    const long long patches = (long long)N * tiles_y * tiles_x;
+    TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c3): too many patches");
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    const long long want = 4ll * cus;                        // 30 KB of LDS per workgroup: four stay resident per CU
+    dim3 grid((unsigned)(patches < want ? patches : want)), block(256);
+    const int P = (int)patches, nt = Cout / 16;
+#define TY1_C3P(PL, NTV) conv3x3_c3p_kernel<PL, NTV><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P)
+    if (pool) {
+        if (nt == 1) TY1_C3P(true, 1); else if (nt == 2) TY1_C3P(true, 2); else if (nt == 3) TY1_C3P(true, 3); else TY1_C3P(true, 4);
+    } else {
+        if (nt == 1) TY1_C3P(false, 1); else if (nt == 2) TY1_C3P(false, 2); else if (nt == 3) TY1_C3P(false, 3); else TY1_C3P(false, 4);
+    }
+#undef TY1_C3P
+    return check_launch("ty1_conv3x3(c3)");
 }
 
 }  // namespace ty1

@@ -1117,6 +1117,9 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
         const double px = (double)N * H * W;
         ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s, 2.0 * px * Cout * 27,
                             4.0 * (px * 3 + 27.0 * Cout + px * Cout / (pool ? 4 : 1)));
+        static const char *old_c3 = getenv("TY1_OLD_C3");             // developer override
+        if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !old_c3)
+            return ty1::conv3x3_c3_persistent(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
         if (pool)
             launch_c3<true>(Cout / 16, grid, s, x, w, scale, shift, y, N, H, W, Cout, alpha);
         else
