@@ -802,45 +802,60 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict
     const int logical = tile_begin + tile_local;
     const int mt = mt_fastest ? logical % mtiles : logical / ntiles;
     const int nt = mt_fastest ? logical / mtiles : logical % ntiles;
-    constexpr int ROWS = POOL ? BM / 4 : BM, C4 = BN / 4;
-    const long long split_stride = (long long)tiles * BM * BN;
-    const float *base = part + (long long)tile_local * BM * BN;
-    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < ROWS * C4; idx += 256 * gridDim.y) {
+    constexpr int C4 = BN / 4;
+    const size_t split_stride = (size_t)tiles * BM * BN;
+    const float *base = part + (size_t)tile_local * BM * BN;
+    // a thread owns four consecutive channels of ONE GEMM row; the slabs are summed with four independent
+    // accumulators so that the loads of a thread are all in flight together
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < BM * C4; idx += 256 * gridDim.y) {
         const int r = idx / C4, c = (idx - r * C4) * 4;
         const int n = nt * BN + c;
-        if (n >= Cout) continue;
-        const float4 sc = *reinterpret_cast<const float4 *>(scale + n), sh = *reinterpret_cast<const float4 *>(shift + n);
-        float4 res;
+        const float *src = base + r * BN + c;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(src + (size_t)s * split_stride);
+            const float4 p1 = *reinterpret_cast<const float4 *>(src + (size_t)(s + 1) * split_stride);
+            const float4 p2 = *reinterpret_cast<const float4 *>(src + (size_t)(s + 2) * split_stride);
+            const float4 p3 = *reinterpret_cast<const float4 *>(src + (size_t)(s + 3) * split_stride);
+            a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+            a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+            a2.x += p2.x; a2.y += p2.y; a2.z += p2.z; a2.w += p2.w;
+            a3.x += p3.x; a3.y += p3.y; a3.z += p3.z; a3.w += p3.w;
+        }
+        for (; s < splits; ++s) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(src + (size_t)s * split_stride);
+            a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+        }
+        float4 v;
+        v.x = (a0.x + a1.x) + (a2.x + a3.x); v.y = (a0.y + a1.y) + (a2.y + a3.y);
+        v.z = (a0.z + a1.z) + (a2.z + a3.z); v.w = (a0.w + a1.w) + (a2.w + a3.w);
+        if (n < Cout) {
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + n), sh = *reinterpret_cast<const float4 *>(shift + n);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            v.x = v.x > 0.f ? v.x : v.x * alpha; v.y = v.y > 0.f ? v.y : v.y * alpha;
+            v.z = v.z > 0.f ? v.z : v.z * alpha; v.w = v.w > 0.f ? v.w : v.w * alpha;
+        }
         if (POOL) {
-            float4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int s = 0; s < splits; ++s) {
-                    const float4 p4 = *reinterpret_cast<const float4 *>(base + s * split_stride + (4 * r + q) * BN + c);
-                    s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
-                }
-                s4.x = s4.x * sc.x + sh.x; s4.y = s4.y * sc.y + sh.y; s4.z = s4.z * sc.z + sh.z; s4.w = s4.w * sc.w + sh.w;
-                v[q].x = s4.x > 0.f ? s4.x : s4.x * alpha; v[q].y = s4.y > 0.f ? s4.y : s4.y * alpha;
-                v[q].z = s4.z > 0.f ? s4.z : s4.z * alpha; v[q].w = s4.w > 0.f ? s4.w : s4.w * alpha;
+            // rows 4w .. 4w+3 of a window sit in the four threads idx, idx + C4, idx + 2*C4, idx + 3*C4; C4 is 16 or 32
+            // lanes, so with 256-thread blocks they are in different waves when C4 = 32 -> go through LDS
+            __shared__ float4 red[256];
+            red[threadIdx.x] = v;
+            __syncthreads();
+            // thread layout inside the block: t = rr * C4 + cc with rr = 256 / C4 consecutive rows (a multiple of 4)
+            const int rr = threadIdx.x / C4;
+            if ((rr & 3) == 0 && n < Cout) {
+                const float4 v1 = red[threadIdx.x + C4], v2 = red[threadIdx.x + 2 * C4], v3 = red[threadIdx.x + 3 * C4];
+                float4 o;
+                o.x = fmaxf(fmaxf(v.x, v1.x), fmaxf(v2.x, v3.x)); o.y = fmaxf(fmaxf(v.y, v1.y), fmaxf(v2.y, v3.y));
+                o.z = fmaxf(fmaxf(v.z, v1.z), fmaxf(v2.z, v3.z)); o.w = fmaxf(fmaxf(v.w, v1.w), fmaxf(v2.w, v3.w));
+                const int win = mt * (BM / 4) + (r >> 2);
+                if (win * 4 < M) *reinterpret_cast<float4 *>(y + (size_t)win * Cout + n) = o;
             }
-            res.x = fmaxf(fmaxf(v[0].x, v[1].x), fmaxf(v[2].x, v[3].x));
-            res.y = fmaxf(fmaxf(v[0].y, v[1].y), fmaxf(v[2].y, v[3].y));
-            res.z = fmaxf(fmaxf(v[0].z, v[1].z), fmaxf(v[2].z, v[3].z));
-            res.w = fmaxf(fmaxf(v[0].w, v[1].w), fmaxf(v[2].w, v[3].w));
-            const int win = mt * (BM / 4) + r;
-            if (win * 4 < M) *reinterpret_cast<float4 *>(y + (long long)win * Cout + n) = res;
-        } else {
-            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < splits; ++s) {
-                const float4 p4 = *reinterpret_cast<const float4 *>(base + s * split_stride + r * BN + c);
-                s4.x += p4.x; s4.y += p4.y; s4.z += p4.z; s4.w += p4.w;
-            }
-            s4.x = s4.x * sc.x + sh.x; s4.y = s4.y * sc.y + sh.y; s4.z = s4.z * sc.z + sh.z; s4.w = s4.w * sc.w + sh.w;
-            res.x = s4.x > 0.f ? s4.x : s4.x * alpha; res.y = s4.y > 0.f ? s4.y : s4.y * alpha;
-            res.z = s4.z > 0.f ? s4.z : s4.z * alpha; res.w = s4.w > 0.f ? s4.w : s4.w * alpha;
+            __syncthreads();
+        } else if (n < Cout) {
             const int m = mt * BM + r;
-            if (m < M) *reinterpret_cast<float4 *>(y + (long long)m * Cout + n) = res;
+            if (m < M) *reinterpret_cast<float4 *>(y + (size_t)m * Cout + n) = v;
         }
     }
 }
@@ -1084,7 +1099,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     if (p.rem) {
         snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", c.H, c.Cin, c.Cout);
         ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
-        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, 16), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
+        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, BM * BN / 4 / 256 < 32 ? BM * BN / 4 / 256 : 32), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
                                                                        p.rem, p.splits, c.alpha);
         return ty1::check_launch("conv_fixup");
     }
