@@ -1,5 +1,6 @@
-# developer tool: run tools/layer_bench.py under several kernel variants
-for e in ${TILES:-default 128x128 128x64 64x64}; do
-  echo "== tile=$e"
-  TY1_TILE=$e timeout -k 5 60 python tools/layer_bench.py --layers ${LAYERS:-2,3,4,5,6,7} --iters 20 2>&1 | grep "shape\|^L" || exit 1
+# developer tool: A/B two builds of libty1.so inside one GPU call (devices differ by several % between calls)
+# usage: tools/abl.sh  [LAYERS=2,3,4,5]  -- compares yolo_amd/lib/libty1_prev.so with yolo_amd/lib/libty1.so
+for lib in ${LIBS:-libty1_prev.so libty1.so libty1_prev.so libty1.so}; do
+  echo "== $lib"
+  TY1_LIB=$PWD/yolo_amd/lib/$lib timeout -k 5 90 python tools/layer_bench.py --layers ${LAYERS:-0,1,2,3,4,5,6,7} --iters 20 ${SHAPES:+--shapes "$SHAPES"} 2>&1 | grep "shape\|^L" || exit 1
 done

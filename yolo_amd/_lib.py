@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libty1.so')
+# TY1_LIB points a developer A/B run at another build of the same library (tools/abl.sh)
+LIB_PATH = os.environ.get('TY1_LIB') or os.path.join(_HERE, 'lib', 'libty1.so')
 
 _c = ctypes
 _vp, _i, _f, _d, _i64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_int64

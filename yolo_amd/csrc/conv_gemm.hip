@@ -580,6 +580,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             const unsigned off = lr.b_base[p] == kOOB ? kOOB : lr.b_base[p] + koff;
             rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
         }
+    };
+    // Cursor step, kept apart from the loads: its branch sits at the very end of the main loop body, so that body is
+    // ONE basic block and the scheduler can spread the address arithmetic and the loads between the MFMAs.
+    auto advance = [&]() {
         ++ld_kc;
         ld_ci0 += BK;
         const bool wrap = ld_ci0 == a.Cin;
@@ -663,8 +667,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     const int h = lane >> 5;
 
     load_chunk();
+    advance();
     store_chunk(0);
     load_chunk();
+    advance();
     __syncthreads();
     zero_f1();
     int buf = 0;
@@ -700,6 +706,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             __builtin_amdgcn_sched_barrier(0);
             buf ^= 1;
             read_frag(f0, buf, 0);                // first k-block of the next chunk (of the next item at an item end)
+            advance();
         }
         mfma(f1, 2, 4);
         if (a.stamp) t1 = __builtin_amdgcn_s_memtime();
