@@ -9,6 +9,7 @@ from yolo_amd import ops, _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='64,16,512,1024,0')
 ap.add_argument('--persist', action='store_true', help='stamps written by conv_persist_kernel')
+ap.add_argument('--direct', action='store_true', help='stamps written by the first-layer persistent kernel (TY1_DEV_STAMPS build)')
 ap.add_argument('--launches', type=int, default=30)
 args = ap.parse_args()
 n, hh, cin, cout, pool = (int(v) for v in args.shape.split(','))
@@ -16,15 +17,17 @@ dev = 'cuda:0'
 x = torch.rand((n, hh, hh, cin), device=dev)
 w = torch.randn((cout, 3, 3, cin), device=dev) * 0.05
 sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-out = ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool))
+nws = ops.conv3x3_workspace_bytes(n, hh, hh, cin, cout, pool)
+ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+out = ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), workspace=ws)
 for _ in range(3):
-    ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out)
+    ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out, workspace=ws)
 cap = 1 << 16
 buf = torch.zeros((cap, 8), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 _lib.call('ty1_debug_stamp_buffer', buf.data_ptr(), cap)
 for _ in range(args.launches):                      # back to back: the last launch's stamps survive (sustained clocks)
-    ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out)
+    ops.conv3x3_bn_leaky(x, w, sc, sh, bool(pool), out=out, workspace=ws)
 torch.cuda.synchronize()
 _lib.call('ty1_debug_stamp_buffer', None, 0)
 ball = buf.cpu().numpy()
@@ -32,6 +35,16 @@ b = ball[:cap // 2]
 b = b[b[:, 0] != 0]
 nb = len(b)
 t0 = b[:, 0].min()
+if args.direct:
+    st, end = (b[:, 0] - t0) / 100.0, (b[:, 3] - t0) / 100.0
+    ni = np.maximum(b[:, 7], 1).astype(np.float64)
+    sto, bar = (b[:, 6] & 0xFFFFFFFF), (b[:, 6] >> 32)
+    print(f'persistent blocks {len(b)}  span {end.max():.1f} us  patches/block min {ni.min():.0f} max {ni.max():.0f}')
+    print(f'per patch (s_memtime ticks): fetch-issue {np.mean(b[:, 2] / ni):.0f}  mfma+epilogue {np.mean(b[:, 1] / ni):.0f}  '
+          f'lds-store {np.mean(sto / ni):.0f}  barrier {np.mean(bar / ni):.0f}   block time {np.mean(end - st):.1f} us -> {np.mean((end - st) / ni):.2f} us per patch')
+    print('end-time histogram:', np.histogram(end, bins=8)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
+    print('start-time histogram:', np.histogram(st, bins=8)[0].tolist(), f'first {st.min():.1f} last {st.max():.1f}')
+    sys.exit(0)
 if args.persist:
     st, end = (b[:, 0] - t0) / 100.0, (b[:, 3] - t0) / 100.0
     ni = np.maximum(b[:, 7], 1).astype(np.float64)

@@ -31,6 +31,10 @@ inline int check_launch(const char *what) {
     return 0;
 }
 
+// developer timeline buffer (8 x i64 per workgroup), set by ty1_debug_stamp_buffer; see tools/stamp_trace.py
+extern long long *g_stamp;
+extern long long g_stamp_cap;
+
 // conv_direct.hip
 int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
                           int W, int Cout, int pool, float alpha, hipStream_t s);

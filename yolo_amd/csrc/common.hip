@@ -8,6 +8,9 @@
 
 namespace ty1 {
 
+long long *g_stamp = nullptr;
+long long g_stamp_cap = 0;
+
 std::string &last_error() {
     static thread_local std::string e;
     return e;

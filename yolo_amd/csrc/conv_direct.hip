@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
         x0 = tx * TW;
     };
     auto fetch = [&](int p) {
+        p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
         int n, y0, x0;
         decode(p, n, y0, x0);
         const bool live = p < patches;
@@ -193,7 +194,7 @@ template <bool POOL, int NT>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                           float *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
-                                                          int tiles_x, int tiles_y, int patches) {
+                                                          int tiles_x, int tiles_y, int patches, long long *stamp) {
     __shared__ __attribute__((aligned(16))) float tile[2][(C3_TH + 2) * C3_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -222,13 +223,22 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         sh[j] = shift[16 * j + i16];
     }
 
-    float4 stage[C3_PER_THREAD];
+    // Halo staging.  Piece i = tid + 256k of a patch is float4 c = i % 50 of halo row rr = i / 50: image row
+    // y0 - 1 + rr, floats 3*x0 - 4 + 4c ...  The loads go through a buffer resource that spans ONE image, so rows above
+    // and below the image fall outside it and read as zero; only the left / right border needs a test.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 stage[C3_PER_THREAD];
     int st_rr[C3_PER_THREAD], st_c[C3_PER_THREAD];
+    const int row_f = 3 * W;                                 // floats per image row
+    unsigned st_off[C3_PER_THREAD];                          // byte offset of the piece in a patch at (y0, x0) = (1, 0)
+    int st_g[C3_PER_THREAD];                                 // its float index in the image row for x0 = 0
 #pragma unroll
     for (int k = 0; k < C3_PER_THREAD; ++k) {
         const int i = tid + 256 * k;
         st_rr[k] = i < C3_ITEMS ? i / C3_V4 : -1;
         st_c[k] = i - (i / C3_V4) * C3_V4;
+        st_g[k] = i < C3_ITEMS ? 4 * st_c[k] - 4 : -0x40000000;     // a dead piece never passes the border test
+        st_off[k] = (unsigned)((st_rr[k] * row_f + 4 * st_c[k] - 4) * 4);
     }
     auto decode = [&](int p, int &n, int &y0, int &x0) {
         const int tx = p % tiles_x;
@@ -238,30 +248,60 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         y0 = ty * C3_TH;
         x0 = tx * C3_TW;
     };
-    const int row_f = 3 * W;                                 // floats per image row
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
     auto fetch = [&](int p) {
+        p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
         int n, y0, x0;
         decode(p, n, y0, x0);
+        n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);
         const bool live = p < patches;
-        const float *img = x + (size_t)n * H * row_f;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x) + (live ? (long long)n * H * row_f : 0ll), 0, live ? H * row_f * 4 : 0, 0x00020000);
+        const unsigned patch_off = (unsigned)(((y0 - 1) * row_f + 3 * x0) * 4);   // wraps for y0 = 0: outside the resource
 #pragma unroll
         for (int k = 0; k < C3_PER_THREAD; ++k) {
-            const int yy = y0 - 1 + st_rr[k], g0 = 3 * x0 - 4 + 4 * st_c[k];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live && st_rr[k] >= 0 && yy >= 0 && yy < H && g0 >= 0 && g0 + 3 < row_f)
-                v = *reinterpret_cast<const float4 *>(img + (size_t)yy * row_f + g0);
-            stage[k] = v;
+            const bool in_row = (unsigned)(st_g[k] + 3 * x0) < (unsigned)row_f;
+            stage[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(in_row ? st_off[k] + patch_off : kOOB), 0, 0);
         }
     };
     auto store = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < C3_PER_THREAD; ++k)
-            if (st_rr[k] >= 0) *reinterpret_cast<float4 *>(&tile[buf][st_rr[k] * C3_ROW + 4 * st_c[k]]) = stage[k];
+            if (st_rr[k] >= 0) *reinterpret_cast<u32x4 *>(&tile[buf][st_rr[k] * C3_ROW + 4 * st_c[k]]) = stage[k];
     };
 
     // pixel of this lane inside an M-tile: window (i16>>2) of 4, position q = i16&3 in the 2x2 window
     const int q = i16 & 3;
     const int lane_px = 2 * (i16 >> 2) + (q & 1), lane_py = q >> 1;
+    // LDS float index of this lane's A element for k step ks in M-tile (pr = 0, wcol = 0) of buffer 0; halo float 0
+    // of a row is image float 3*x0 - 4, so pixel x0 - 1 starts at 1.  Every other tile is a compile-time offset.
+    int a_addr[7];
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) a_addr[ks] = (4 * wave + lane_py) * C3_ROW + lane_px * 3 + 1 + koff[ks];
+    const float *lds = &tile[0][0];
+
+    // Output: lane holds channel 16j + i16 of pool window kq (POOL) / of the 2x2 pixels of window kq, for every
+    // M-tile t = (pr, wc): pooled row 2*wave + pr, windows 4*wc + kq.  Stores go through a buffer resource based at
+    // the patch's first output element, so a store is one 32-bit offset: lane part + compile-time tile part.
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    const unsigned row_b = (unsigned)Wo * Cout * 4u, px_b = (unsigned)Cout * 4u;
+    const unsigned lane_off = POOL ? (unsigned)(2 * wave) * row_b + (unsigned)kq * px_b + (unsigned)i16 * 4u
+                                   : (unsigned)(4 * wave) * row_b + (unsigned)(2 * kq) * px_b + (unsigned)i16 * 4u;
+    const long long y_total = (long long)NB * Ho * Wo * Cout;
+
+    // developer stamps (compiled in with -DTY1_DEV_STAMPS only: the fences change the schedule)
+#ifdef TY1_DEV_STAMPS
+#define C3_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define C3_STAMP(var) do { } while (0)
+#endif
+    long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_fetch = 0, acc_mma = 0, acc_store = 0, acc_bar = 0, n_done = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4;
+    if (stamp && tid == 0) {
+        stamp[(long long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        stamp[(long long)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        stamp[(long long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
 
     int p = blockIdx.x;
     fetch(p);
@@ -269,69 +309,137 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     __syncthreads();
     int buf = 0;
     for (; p < patches; p += gridDim.x) {
+        C3_STAMP(ts0);
         fetch(p + gridDim.x);                                // in flight during the MFMAs (nothing past the end)
+        C3_STAMP(ts1);
         int n, y0, x0;
         decode(p, n, y0, x0);
-        const float *tl = tile[buf];
-        for (int t2 = 0; t2 < 16; t2 += 2) {                 // two M-tiles per iteration (independent chains)
-            f32x4 acc[2][NT];
-            int base[2];
+        n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);
+        const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+        const long long o_org = (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
+        const long long o_left = (y_total - o_org) * 4;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        // output rows / columns of the image left from this lane's first element (a tile is valid below them)
+        const int rows_left = Ho - oy0 - (POOL ? 2 : 4) * wave;
+        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * kq;
+        int ab[7];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int t = t2 + u;
-                const int pr = t >> 3, wcol = (t & 7) * 4;   // pooled row in the wave's strip, first window
-                const int py = 4 * wave + 2 * pr + lane_py, px = 2 * wcol + lane_px;
-                base[u] = py * C3_ROW + px * 3 + 1;          // halo float 0 is image float 3*x0 - 4: pixel x0-1 starts at 1
+        for (int ks = 0; ks < 7; ++ks) ab[ks] = a_addr[ks] + buf * ((C3_TH + 2) * C3_ROW);
+
+        // Two M-tiles (independent MFMA chains) per step; the BN / LeakyReLU / pool / store of a step is written
+        // after the MFMAs of the NEXT step so that the scheduler can run it under them.
+        // A operands of a step (7 k-steps x 2 tiles) are read from LDS one whole step ahead of their MFMAs
+        auto load_a = [&](int t2, float (&av)[7][2]) {
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t2 + u, pr = t >> 3, wc = t & 7;
+                    av[ks][u] = lds[ab[ks] + 2 * pr * C3_ROW + 24 * wc];   // window 4*wc -> pixel 8*wc -> float 24*wc
+                }
+        };
+        auto compute = [&](const float (&av)[7][2], f32x4 (&acc)[2][NT]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks) {
-                const float a0 = tl[base[0] + koff[ks]];
-                const float a1 = tl[base[1] + koff[ks]];
+            for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wreg[j][ks], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wreg[j][ks], acc[1][j], 0, 0, 0);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][0], wreg[j][ks], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][1], wreg[j][ks], acc[1][j], 0, 0, 0);
                 }
-            }
-            // epilogue: this lane holds pool window (wcol + kq) of pooled row pr, channel 16j + i16
+        };
+        auto finish = [&](int t2, const f32x4 (&acc)[2][NT]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int t = t2 + u;
-                const int pr = t >> 3, win = (t & 7) * 4 + kq;
+                const int t = t2 + u, pr = t >> 3, wc = t & 7;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const int co = 16 * j + i16;
-                    float v[4];
+                    float z[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[u][j][r] * sc[j] + sh[j];
-                        v[r] = z > 0.f ? z : z * alpha;
-                    }
+                    for (int r = 0; r < 4; ++r) z[r] = acc[u][j][r] * sc[j] + sh[j];
                     if (POOL) {
-                        const int oy = (y0 >> 1) + 2 * wave + pr, ox = (x0 >> 1) + win;
-                        if (oy < (H >> 1) && ox < (W >> 1))
-                            y[(((size_t)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
+                        const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+                        const float v = m > 0.f ? m : m * alpha;
+                        const bool ok = pr < rows_left && 4 * wc < cols_left;
+                        const unsigned off = ok ? lane_off + (unsigned)pr * row_b + (unsigned)(4 * wc) * px_b + 64u * j : kOOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int oy = y0 + 4 * wave + 2 * pr + (r >> 1), ox = x0 + 2 * win + (r & 1);
-                            if (oy < H && ox < W) y[(((size_t)n * H + oy) * W + ox) * Cout + co] = v[r];
+                            const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
+                            const int dy = 2 * pr + (r >> 1), dx = 8 * wc + (r & 1);
+                            const bool ok = dy < rows_left && dx < cols_left;
+                            const unsigned off = ok ? lane_off + (unsigned)dy * row_b + (unsigned)dx * px_b + 64u * j : kOOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
                         }
                     }
                 }
             }
+        };
+        f32x4 accA[2][NT], accB[2][NT];
+        float avA[7][2], avB[7][2];
+        load_a(0, avA);
+        load_a(2, avB);
+        compute(avA, accA);
+        // the fences pin "reads of the step after next | MFMAs of the next step + epilogue of this one" as stages
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < 3) load_a(4 * it + 4, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(avB, accB);
+            finish(4 * it, accA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < 3) load_a(4 * it + 6, avB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < 3) compute(avA, accA);
+            finish(4 * it + 2, accB);
         }
+        C3_STAMP(ts2);
         store(buf ^ 1);                                      // that buffer was last read before the previous barrier
+        C3_STAMP(ts3);
         __syncthreads();
+        C3_STAMP(ts4);
         buf ^= 1;
+        acc_fetch += ts1 - ts0; acc_mma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3; ++n_done;
+    }
+#undef C3_STAMP
+    if (stamp && tid == 0) {
+        stamp[(long long)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        stamp[(long long)blockIdx.x * 8 + 1] = acc_mma;
+        stamp[(long long)blockIdx.x * 8 + 2] = acc_fetch;
+        stamp[(long long)blockIdx.x * 8 + 6] = acc_store + (acc_bar << 32);
+        stamp[(long long)blockIdx.x * 8 + 7] = n_done;
     }
 }
 
 }  // namespace
 
 namespace ty1 {
+
+namespace {
+int cu_count() {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return cus;
+}
+// workgroups of `kernel` (256 threads, static LDS) that one CU keeps resident, at most `cap`; `env` is a developer override
+template <typename K>
+int resident_blocks(K kernel, int cap, const char *env) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
+    if (const char *e = getenv(env)) occ = atoi(e) > 0 ? atoi(e) : occ;
+    else if (occ > cap) occ = cap;
+    if (getenv("TY1_VERBOSE")) fprintf(stderr, "[ty1] %s: %d resident workgroups per CU\n", env, occ);
+    return occ;
+}
+}  // namespace
 
 // Cin == 16, Cout == 32 or 64.  Returns 0 on success (error text via ty1::fail).
 int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
@@ -342,19 +450,21 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
     const double px = (double)N * H * W;
     ProfScope prof(pool ? "conv3x3_c16_pool" : "conv3x3_c16", s, 2.0 * px * Cout * 144,
                    4.0 * (px * 16 + 144.0 * Cout + px * Cout / (pool ? 4 : 1)));
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-        cus = 256;
-    const long long want = 2ll * cus;                        // persistent: two workgroups (59 KB of LDS each) per CU
-    dim3 grid((unsigned)(patches < want ? patches : want)), block(256);
     const int P = (int)patches;
+    // persistent grid: the workgroups that stay resident (59 KB of LDS each: two per CU when the registers allow)
+#define TY1_C16(PL, NTV)                                                                                              \
+    do {                                                                                                              \
+        static const int per_cu = resident_blocks(conv3x3_c16_kernel<PL, NTV>, 2, "TY1_C16_BLOCKS");                  \
+        const long long want = (long long)per_cu * cu_count();                                                        \
+        conv3x3_c16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(          \
+            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);                                        \
+    } while (0)
     if (Cout == 32) {
-        if (pool) conv3x3_c16_kernel<true, 1><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
-        else conv3x3_c16_kernel<false, 1><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+        if (pool) TY1_C16(true, 1); else TY1_C16(false, 1);
     } else {
-        if (pool) conv3x3_c16_kernel<true, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
-        else conv3x3_c16_kernel<false, 2><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);
+        if (pool) TY1_C16(true, 2); else TY1_C16(false, 2);
     }
+#undef TY1_C16
     return check_launch("ty1_conv3x3(c16)");
 }
 
@@ -365,13 +475,17 @@ int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, co
     const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
     const long long patches = (long long)N * tiles_y * tiles_x;
     TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c3): too many patches");
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-        cus = 256;
-    const long long want = 4ll * cus;                        // 30 KB of LDS per workgroup: four stay resident per CU
-    dim3 grid((unsigned)(patches < want ? patches : want)), block(256);
+    TY1_REQUIRE((long long)H * W * 12 < (1ll << 31), "ty1_conv3x3(c3): one image must stay below 2 GiB");
     const int P = (int)patches, nt = Cout / 16;
-#define TY1_C3P(PL, NTV) conv3x3_c3p_kernel<PL, NTV><<<grid, block, 0, s>>>(x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P)
+    // persistent grid: as many workgroups as stay resident (30 KB of LDS, <= 128 registers: four per CU)
+#define TY1_C3P(PL, NTV)                                                                                              \
+    do {                                                                                                              \
+        static const int per_cu = resident_blocks(conv3x3_c3p_kernel<PL, NTV>, 4, "TY1_C3_BLOCKS");                   \
+        const long long want = (long long)per_cu * cu_count();                                                        \
+        const long long nblk = patches < want ? patches : want;                                                       \
+        conv3x3_c3p_kernel<PL, NTV><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                       \
+            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr); \
+    } while (0)
     if (pool) {
         if (nt == 1) TY1_C3P(true, 1); else if (nt == 2) TY1_C3P(true, 2); else if (nt == 3) TY1_C3P(true, 3); else TY1_C3P(true, 4);
     } else {

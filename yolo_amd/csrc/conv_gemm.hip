@@ -59,8 +59,8 @@ struct ConvArgs {
     long long stamp_cap; // rows of 8 i64 in stamp
 };
 
-long long *g_stamp = nullptr;     // set by ty1_debug_stamp_buffer (developer tool, tools/stamp_trace.py)
-long long g_stamp_cap = 0;
+using ty1::g_stamp;
+using ty1::g_stamp_cap;
 
 __device__ __forceinline__ void stamp(const ConvArgs &a, int slot) {
     if (a.stamp && threadIdx.x == 0) {
@@ -1140,7 +1140,8 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
         ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s, 2.0 * px * Cout * 27,
                             4.0 * (px * 3 + 27.0 * Cout + px * Cout / (pool ? 4 : 1)));
         static const char *old_c3 = getenv("TY1_OLD_C3");             // developer override
-        if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && !old_c3)
+        // (the persistent kernel pools before it activates, which needs a non-decreasing LeakyReLU: alpha >= 0)
+        if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && alpha >= 0.f && !old_c3)
             return ty1::conv3x3_c3_persistent(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
         if (pool)
             launch_c3<true>(Cout / 16, grid, s, x, w, scale, shift, y, N, H, W, Cout, alpha);
