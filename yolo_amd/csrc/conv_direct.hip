@@ -14,7 +14,10 @@
 //   - an MFMA tile is 32 pixels = 8 pool windows (2 rows x 16 columns), rows ordered m = 4*window + (dy*2+dx), so the
 //     four pixels of a window are the four consecutive accumulator registers of a lane (C/D row = (r&3) + 8(r>>2) +
 //     4(lane>>5)) and the max-pool is three v_max in registers;
-//   - one ds_read_b128 feeds four MFMAs (ci = 8g + 4h + j, j = 0..3); a wave owns 2 rows x 32 columns = two tiles.
+//   - one ds_read_b128 feeds four MFMAs (ci = 8g + 4h + j, j = 0..3); a wave owns 2 rows x 32 columns = two tiles;
+//   - halo loads and output stores are buffer instructions (out-of-range offset = zero / dropped), so the patch loop
+//     has no branches; with Cout = 32 the epilogue of a patch is issued between the MFMAs of the next one (second
+//     accumulator set), and the pool runs before the activation (LeakyReLU with alpha >= 0 is non-decreasing).
 // Two workgroups (2 x 29.4 KB of LDS each) share a CU.
 #include "common.h"
 
@@ -55,44 +58,49 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     }
 
     // ---- halo staging through registers: fetch patch p+1 while patch p multiplies, store it after the MFMAs
-    //      rows y0-1 .. y0+TH, pixels x0-1 .. x0+TW, 4 x 16-byte pieces per pixel, zero outside the image
-    float4 stage[STAGE_PER_THREAD];
-    int lds_off[STAGE_PER_THREAD], st_rr[STAGE_PER_THREAD], st_pp[STAGE_PER_THREAD];
+    //      rows y0-1 .. y0+TH, pixels x0-1 .. x0+TW, 4 x 16-byte pieces per pixel.  The loads go through a buffer
+    //      resource spanning ONE image: rows above / below it fall outside and read as zero, only the left / right
+    //      border needs a test.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
+    u32x4 stage[STAGE_PER_THREAD];
+    int lds_off[STAGE_PER_THREAD], st_pp[STAGE_PER_THREAD];
+    unsigned st_off[STAGE_PER_THREAD];                       // byte offset of the piece in a patch at (y0, x0) = (1, 1)
 #pragma unroll
     for (int k = 0; k < STAGE_PER_THREAD; ++k) {
         const int i = tid + 256 * k;
         const int piece = i & 3, pix = i >> 2;
-        st_rr[k] = pix / (TW + 2);
-        st_pp[k] = pix - st_rr[k] * (TW + 2);
-        lds_off[k] = i < STAGE_ITEMS ? st_rr[k] * RS + st_pp[k] * CS + piece * 4 : -1;
+        const int rr = pix / (TW + 2);
+        st_pp[k] = i < STAGE_ITEMS ? pix - rr * (TW + 2) : -0x40000000;     // a dead piece never passes the border test
+        lds_off[k] = i < STAGE_ITEMS ? rr * RS + (pix - rr * (TW + 2)) * CS + piece * 4 : -1;
+        st_off[k] = (unsigned)(((rr * W + (pix - rr * (TW + 2))) * CIN + piece * 4) * 4);
     }
     auto decode = [&](int p, int &n, int &y0, int &x0) {
+        p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
         const int tx = p % tiles_x;
         const int r = p / tiles_x;
         const int ty = r % tiles_y;
-        n = r / tiles_y;
-        y0 = ty * TH;
-        x0 = tx * TW;
+        n = __builtin_amdgcn_readfirstlane(r / tiles_y);
+        y0 = __builtin_amdgcn_readfirstlane(ty * TH);
+        x0 = __builtin_amdgcn_readfirstlane(tx * TW);
     };
     auto fetch = [&](int p) {
-        p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
         int n, y0, x0;
         decode(p, n, y0, x0);
         const bool live = p < patches;
-        const float *img = x + (size_t)n * H * W * CIN;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x) + (live ? (long long)n * H * W * CIN : 0ll), 0, live ? H * W * CIN * 4 : 0, 0x00020000);
+        const unsigned patch_off = (unsigned)((((y0 - 1) * W + x0 - 1) * CIN) * 4);   // wraps for y0 = 0: outside the resource
 #pragma unroll
         for (int k = 0; k < STAGE_PER_THREAD; ++k) {
-            const int yy = y0 - 1 + st_rr[k], xx = x0 - 1 + st_pp[k];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live && lds_off[k] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                v = *reinterpret_cast<const float4 *>(img + ((size_t)yy * W + xx) * CIN + ((tid + 256 * k) & 3) * 4);
-            stage[k] = v;
+            const bool in_row = (unsigned)(st_pp[k] + x0 - 1) < (unsigned)W;
+            stage[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(in_row ? st_off[k] + patch_off : kOOB), 0, 0);
         }
     };
     auto store = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < STAGE_PER_THREAD; ++k)
-            if (lds_off[k] >= 0) *reinterpret_cast<float4 *>(&tile[buf][lds_off[k]]) = stage[k];
+            if (lds_off[k] >= 0) *reinterpret_cast<u32x4 *>(&tile[buf][lds_off[k]]) = stage[k];
     };
 
     // ---- this lane's pixel inside an MFMA tile: window wdw = (lane&31)>>2 of 8 along x, q = lane&3 inside the window
@@ -100,6 +108,55 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     const int lane_off = (q >> 1) * RS + (2 * wdw + (q & 1)) * CS + 4 * h;    // + tile origin + tap offset + 8g
     const int prow = 2 * wave;                               // wave owns pixel rows 2*wave, 2*wave+1 of the patch
     const int base0 = prow * RS + lane_off, base1 = base0 + 16 * CS;          // tile columns 0 and 1 (16 pixels apart)
+
+    // ---- output: register group gq = r>>2 with lane half h is window wx = 8u + 2gq + h of the wave's row pair, r&3
+    //      the position inside it.  Stores go through a buffer resource based at the patch's first output element:
+    //      one 32-bit offset = lane part + compile-time piece part.
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    const unsigned row_b = (unsigned)Wo * Cout * 4u, px_b = (unsigned)Cout * 4u;
+    const unsigned out_lane = POOL ? (unsigned)wave * row_b + (unsigned)h * px_b + (unsigned)col * 4u
+                                   : (unsigned)(2 * wave) * row_b + (unsigned)(2 * h) * px_b + (unsigned)col * 4u;
+    const long long y_total = (long long)NB * Ho * Wo * Cout;
+    // piece idx = 4u + gq of patch (n, y0, x0); n < 0: nothing is stored
+    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], int n, int y0, int x0) {
+        const int u = idx >> 2, gq = idx & 3;
+        const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+        const long long o_org = n < 0 ? 0ll : (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
+        const long long o_left = n < 0 ? 0ll : (y_total - o_org) * 4;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        const int rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
+        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = acc[u][nt][4 * gq + r] * sc[nt] + sh[nt];
+            if (POOL) {
+                // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
+                const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+                const float v = m > 0.f ? m : m * alpha;
+                const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
+                const unsigned off = ok ? out_lane + (unsigned)(8 * u + 2 * gq) * px_b + 128u * nt : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
+                    const int dy = r >> 1, dx = 2 * (8 * u + 2 * gq) + (r & 1);
+                    const bool ok = dy < rows_left && dx < cols_left;
+                    const unsigned off = ok ? out_lane + (unsigned)dy * row_b + (unsigned)dx * px_b + 128u * nt : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+                }
+            }
+        }
+    };
+
+    // With one channel tile per wave there are registers for a second accumulator set: the epilogue of a patch is
+    // then issued between the MFMAs of the NEXT patch (one piece per tap) instead of after its own.
+    constexpr bool PIPE = NT == 1;
+    f32x16 acc[2][NT], prev[2][PIPE ? NT : 1];
+    int pn = -1, py0 = 0, px0 = 0;
 
     int p = blockIdx.x;
     fetch(p);
@@ -110,7 +167,6 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
         fetch(p + gridDim.x);                               // lands during the MFMAs below (nothing past the end)
         int n, y0, x0;
         decode(p, n, y0, x0);
-        f32x16 acc[2][NT];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -138,38 +194,28 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
                     acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wv.w, acc[1][nt], 0, 0, 0);
                 }
             }
+            if constexpr (PIPE) {
+                if (t < 8) epi_piece(t, prev, pn, py0, px0);
+            }
         }
         store(buf ^ 1);                                     // that buffer was last read before the previous barrier
-        // ---- epilogue: register group gq = r>>2 with lane half h is window 2*gq + h of the tile; r&3 = position in it
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = 32 * nt + col;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[u][nt][4 * gq + r] * sc[nt] + sh[nt];
-                        v[r] = z > 0.f ? z : z * alpha;
-                    }
-                    const int wx = 8 * u + 2 * gq + h;                      // window column inside the patch row pair
-                    if (POOL) {
-                        const int oy = (y0 + prow) >> 1, ox = (x0 >> 1) + wx;
-                        if (oy < (H >> 1) && ox < (W >> 1))
-                            y[(((size_t)n * (H >> 1) + oy) * (W >> 1) + ox) * Cout + co] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int oy = y0 + prow + (r >> 1), ox = x0 + 2 * wx + (r & 1);
-                            if (oy < H && ox < W) y[(((size_t)n * H + oy) * W + ox) * Cout + co] = v[r];
-                        }
-                    }
-                }
-            }
+            for (int idx = 0; idx < 8; ++idx) epi_piece(idx, acc, n, y0, x0);
+        }
         __syncthreads();
         buf ^= 1;
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) prev[u][nt] = acc[u][nt];
+            pn = n; py0 = y0; px0 = x0;
+        }
+    }
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) epi_piece(idx, prev, pn, py0, px0);
     }
 }
 

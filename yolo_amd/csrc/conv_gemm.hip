@@ -1162,7 +1162,8 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     const bool p = pool != 0;
 
     static const char *no_direct = getenv("TY1_NO_DIRECT16");          // developer override
-    if (Cin == 16 && (Cout == 32 || Cout == 64) && !no_direct) {       // shallow K: direct kernel, weights in registers
+    // shallow K: direct kernel, weights in registers (it pools before it activates: needs alpha >= 0; one image < 2 GiB)
+    if (Cin == 16 && (Cout == 32 || Cout == 64) && alpha >= 0.f && (long long)H * W * 64 < (1ll << 31) && !no_direct) {
         if (ws_need) return 0;
         return ty1::conv3x3_c16_direct(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
     }
