@@ -556,6 +556,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     long long org_l;
     make_rows(cur, lr, org_l);
 
+    // ---- BN scale / shift of an item's channels (lane holds channel lane&31 of each tile column).  They are
+    //      fetched when the fetch cursor ENTERS the item, i.e. two chunks before its MFMAs start, and the per-chunk
+    //      LDS store that follows in every iteration marks them as arrived (see `landed` below): the epilogue then
+    //      needs no vmcnt wait of its own, which would also wait for the chunk prefetches in flight.
+    float sc_cur[WN], sh_cur[WN], sc_nxt[WN], sh_nxt[WN];
+    auto load_bn = [&](const Desc &d, float (&sc)[WN], float (&sh)[WN]) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = d.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
+            const bool ok = d.live && !d.raw && n < a.Cout;
+            sc[j] = ok ? a.scale[n] : 0.f;
+            sh[j] = ok ? a.shift[n] : 0.f;
+        }
+    };
+    auto landed = [&]() {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(sc_nxt[j]), "+v"(sh_nxt[j]));
+    };
+
     // ---- fetch cursor: two chunks ahead of the MFMAs.  When it reaches the end of its item it moves on to this
     //      block's next item (a block-uniform branch taken once per item: new descriptor, new row geometry).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -593,6 +612,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             ++ld_round;
             nxt = decode(item_of(ld_round));
             make_rows(nxt, lr, org_l);
+            load_bn(nxt, sc_nxt, sh_nxt);
             ld_kc = nxt.kc0;
             ld_end = nxt.kc1;
             ld_tap = nxt.tap0;
@@ -666,6 +686,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     // per-lane epilogue constants that do not depend on the item (scale / shift depend on nt only)
     const int h = lane >> 5;
 
+    load_bn(cur, sc_cur, sh_cur);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { sc_nxt[j] = 0.f; sh_nxt[j] = 0.f; }
     load_chunk();
     advance();
     store_chunk(0);
@@ -680,16 +703,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     while (cur.live) {
         long long t0 = 0, t1 = 0, t2 = 0;
         if (a.stamp) t0 = __builtin_amdgcn_s_memtime();
-        // BN scale / shift of this item's channels: fetched now, used in the epilogue a whole tile later
-        float sc[WN], sh[WN];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = cur.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
-            sc[j] = (!cur.raw && n < a.Cout) ? a.scale[n] : 0.f;
-            sh[j] = (!cur.raw && n < a.Cout) ? a.shift[n] : 0.f;
-        }
         for (int kc = cur.kc0; kc < cur.kc1; ++kc) {
             store_chunk(buf ^ 1);                 // that buffer was last read before the previous barrier
+            landed();                             // (every load older than the chunk just stored has arrived)
             load_chunk();
             mfma(f1, 2, 4);                       // second half of the previous chunk's last k-block (zeros at an item start)
             read_frag(f1, buf, 1);
@@ -751,7 +767,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                             float v[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                float t = acc[i][j][4 * g + q] * sc[j] + sh[j];
+                                float t = acc[i][j][4 * g + q] * sc_cur[j] + sh_cur[j];
                                 v[q] = t > 0.f ? t : t * a.alpha;
                             }
                             const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
@@ -764,7 +780,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float t = acc[i][j][r] * sc[j] + sh[j];
+                            float t = acc[i][j][r] * sc_cur[j] + sh_cur[j];
                             t = t > 0.f ? t : t * a.alpha;
                             const unsigned off = n_ok ? vb + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * row_bytes : kOOB;
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), o_rsrc, (int)off, 0, 0);
@@ -783,6 +799,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 
         // ---- next item becomes current; the fetch cursor is already two chunks inside it
         cur = nxt;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) { sc_cur[j] = sc_nxt[j]; sh_cur[j] = sh_nxt[j]; }
         if (a.stamp) {
             const long long t3 = __builtin_amdgcn_s_memtime();
             t_loop += t1 - t0; t_epi += t2 - t1; t_rows += t3 - t2; ++n_items;
