@@ -70,6 +70,26 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
                                 void *workspace, size_t workspace_bytes, ty1_stream_t stream);
 
 /*
+ * The same block for the bf16 network (BASELINE config "batch=1024 bf16 inference", 128 images per GPU):
+ * activations and weights in bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, folded BN + LeakyReLU + pool
+ * in fp32, output rounded to bf16 (nearest even).  Same reference lines as above
+ * (/root/reference/models/model_tiny_yolov1.py:43-87); the reference itself computes in fp32, parity for this path
+ * is a stated tolerance (tests/test_gpu_bf16.py).
+ *   Cin == 3:  x (N,H,W,3) and w (Cout,3,3,3) are fp32 - the image enters in fp32 and the first layer stays an
+ *              exact-fp32 convolution - y is bf16.  Needs W % 4 == 0, Cout <= 64.
+ *   Cin == 16: x, w, y bf16; Cout 32 or 64.
+ *   Cin % 32 == 0: x, w bf16; Cout % 64 == 0; y bf16, or fp32 when out_f32 != 0 (pool == 0 only: the last conv
+ *              layer feeds the fp32 Dense).
+ *   alpha >= 0.  workspace as for ty1_conv3x3_bn_leaky_ws_f32 (size from ty1_conv3x3_workspace_bytes_bf16; may be NULL).
+ * ty1_cast_f32_to_bf16 converts n floats to bf16 (round to nearest even), e.g. the weights at model load.
+ */
+int ty1_conv3x3_workspace_bytes_bf16(int N, int H, int W, int Cin, int Cout, int pool, size_t *bytes);
+int ty1_conv3x3_bn_leaky_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y,
+                              int N, int H, int W, int Cin, int Cout, int pool, float alpha, int out_f32,
+                              void *workspace, size_t workspace_bytes, ty1_stream_t stream);
+int ty1_cast_f32_to_bf16(const float *x, void *y, long long n, ty1_stream_t stream);
+
+/*
  * Split-K Dense: part[s][n][u] = sum_{k in slice s} x[n][k] * wt[u][k]      (no bias here)
  * Replaces the matmul of Flatten + Dense(1470,'linear',name='connected_0'):
  * /root/reference/models/model_tiny_yolov1.py:89,96.  The bias add and the split-K reduction

@@ -1,0 +1,95 @@
+"""GPU parity of the bf16 conv path (BASELINE config 3: bf16 inference) against the CPU oracle.
+
+The reference computes in fp32 (Keras default floatx), so there is no reference bf16 result: the oracle is
+oracle/model_ref.conv_block_ref (fp32 torch-CPU restatement of models/model_tiny_yolov1.py:43-87) evaluated on the
+SAME bf16-rounded inputs and weights, and the stated tolerance is the output rounding of the kernel:
+|got - ref| <= 2^-8 |ref| + 2e-3   (bf16 keeps 8 significant bits: half an ulp is 2^-9 relative; the factor two covers
+fp32 summation-order differences that move a value across a rounding boundary).  Layers that store fp32 (out_f32)
+are held to the fp32 bar, 1e-3 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+from yolo_amd import ops, params as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _case(N, H, cin, cout, pool, out_f32, seed, use_ws):
+    rng = np.random.default_rng(seed)
+    x = rng.random((N, H, H, cin)).astype(np.float32)
+    w = P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)
+    gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    beta = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
+    mean = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    if cin != 3:                      # what the kernel sees: bf16 activations and weights
+        x, w = bf16_round(x), bf16_round(w)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+    ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
+    scale, shift = ops.fold_bn(gamma, beta, mean, var)
+    in_dt = torch.float32 if cin == 3 else torch.bfloat16
+    ws = None
+    if use_ws:
+        nbytes = ops.conv3x3_workspace_bytes_bf16(N, H, H, cin, cout, pool)
+        ws = torch.full((max(nbytes, 16) // 4,), float('nan'), dtype=torch.float32, device=DEV)
+    got = ops.conv3x3_bn_leaky_bf16(dev(x, in_dt), dev(P.hwio_to_ohwi(w), in_dt), dev(scale), dev(shift), pool,
+                                    out_f32=out_f32, workspace=ws)
+    assert got.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+    return got.float().cpu().numpy(), ref
+
+
+# the eight layers of the network (last one stores fp32 for the Dense), then shapes with tails / no pool / K-split tail
+CASES = [(2, 448, 3, 16, True, False), (2, 224, 16, 32, True, False), (2, 112, 32, 64, True, False),
+         (3, 56, 64, 128, True, False), (3, 28, 128, 256, True, False), (5, 14, 256, 512, True, False),
+         (5, 7, 512, 1024, False, False), (5, 7, 1024, 256, False, True),
+         (1, 36, 3, 32, True, False), (1, 40, 3, 16, False, False), (1, 20, 16, 32, False, False), (1, 22, 16, 64, True, False),
+         (2, 10, 32, 64, True, False), (1, 6, 64, 128, False, True), (70, 7, 64, 64, False, False),
+         (24, 28, 128, 256, True, False), (12, 7, 1024, 256, False, True)]
+
+
+@pytest.mark.parametrize('use_ws', [False, True])
+@pytest.mark.parametrize('N,H,cin,cout,pool,out_f32', CASES)
+def test_conv_block_bf16_vs_oracle(N, H, cin, cout, pool, out_f32, use_ws):
+    if use_ws and cin in (3, 16):
+        pytest.skip('direct kernels have no split path')
+    got, ref = _case(N, H, cin, cout, pool, out_f32, seed=cin + cout, use_ws=use_ws)
+    assert got.shape == ref.shape
+    if out_f32:
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
+    else:
+        err = np.abs(got - ref)
+        assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
+        # and typically exact to the rounding: at least 99 % of the outputs are the nearest bf16 of the oracle value
+        assert (got == bf16_round(ref)).mean() > 0.99
+
+
+def test_cast_bf16_round_to_nearest_even():
+    x = torch.randn(100003, device=DEV) * 37.0
+    assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))
+
+
+def test_bf16_rejects_what_it_does_not_support():
+    x = torch.zeros((1, 8, 8, 48), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((64, 3, 3, 48), dtype=torch.bfloat16, device=DEV)
+    s = torch.ones(64, device=DEV)
+    with pytest.raises(Exception, match='multiple of 32'):
+        ops.conv3x3_bn_leaky_bf16(x, w, s, s, False)
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros((64, 3, 3, 64), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(Exception, match='pool == 0'):
+        ops.conv3x3_bn_leaky_bf16(x, w, s, s, True, out_f32=True)
+    with pytest.raises(Exception, match='alpha'):
+        ops.conv3x3_bn_leaky_bf16(x, w, s, s, False, alpha=-0.1)

@@ -36,8 +36,10 @@ extern long long *g_stamp;
 extern long long g_stamp_cap;
 
 // conv_direct.hip
-int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
-                          int W, int Cout, int pool, float alpha, hipStream_t s);
+int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, void *y, int N, int H,
+                          int W, int Cout, int pool, float alpha, int out_bf16, hipStream_t s);
+int conv3x3_c16_direct_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H,
+                            int W, int Cout, int pool, float alpha, hipStream_t s);
 int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
                        int W, int Cout, int pool, float alpha, hipStream_t s);
 

@@ -221,6 +221,178 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 
 
 // ------------------------------------------------------------------------------------------------
+// The same layer with bf16 activations and weights (fp32 accumulate, bf16 out) on v_mfma_f32_32x32x16_bf16:
+// K = 16 of one MFMA is exactly the 16 input channels of one tap, so a 32-pixel tile is 9 MFMAs per 32 output
+// channels; lane (pixel = lane&31, h = lane>>5) supplies channels 8h..8h+7 = one 16-byte LDS read, the weights
+// of a lane are 9 x 16 bytes per 32 channels.  Halo in LDS: 32-byte pixels, row stride (TW+2)*32 + 16 bytes (an odd
+// number of 16-byte slots: the two pixel rows of a tile then hit different banks).  With 16x fewer matrix cycles per
+// byte than the f32 kernel this one is bound by its HBM traffic (155 MB at batch 64) and the LDS path.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BPX = 32;                                      // bytes per LDS pixel (16 bf16)
+constexpr int BRS = (TW + 2) * BPX + 16;                     // bytes per LDS halo row
+constexpr int BST_ITEMS = (TH + 2) * (TW + 2) * 2;           // 16-byte pieces of one halo
+constexpr int BST_PER_THREAD = (BST_ITEMS + 255) / 256;      // 3
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to nearest even (v_cvt_pk_bf16_f32)
+    const __bf16 hv = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, hv);
+}
+
+template <bool POOL, int NT>
+__global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               unsigned short *__restrict__ y, int NB, int H, int W, int Cout,
+                                                               float alpha, int tiles_x, int tiles_y, int patches) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2][(TH + 2) * BRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
+
+    // ---- weights of this lane: wreg[nt][tap] = w[32nt + col][tap][8h .. 8h+7]   (OHWI bf16, 16 per tap)
+    bf16x8 wreg[NT][9];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            wreg[nt][t] = *reinterpret_cast<const bf16x8 *>(w + ((size_t)(32 * nt + col) * 9 + t) * CIN + 8 * h);
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        sc[nt] = scale[32 * nt + col];
+        sh[nt] = shift[32 * nt + col];
+    }
+
+    // ---- halo staging through registers (see conv3x3_c16_kernel): 2 x 16-byte pieces per pixel
+    u32x4 stage[BST_PER_THREAD];
+    int lds_off[BST_PER_THREAD], st_pp[BST_PER_THREAD];
+    unsigned st_off[BST_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < BST_PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        const int half = i & 1, pix = i >> 1;
+        const int rr = pix / (TW + 2), pp = pix - rr * (TW + 2);
+        st_pp[k] = i < BST_ITEMS ? pp : -0x40000000;
+        lds_off[k] = i < BST_ITEMS ? rr * BRS + pp * BPX + half * 16 : -1;
+        st_off[k] = (unsigned)((rr * W + pp) * (CIN * 2) + half * 16);
+    }
+    auto decode = [&](int p, int &n, int &y0, int &x0) {
+        p = __builtin_amdgcn_readfirstlane(p);
+        const int tx = p % tiles_x;
+        const int r = p / tiles_x;
+        const int ty = r % tiles_y;
+        n = __builtin_amdgcn_readfirstlane(r / tiles_y);
+        y0 = __builtin_amdgcn_readfirstlane(ty * TH);
+        x0 = __builtin_amdgcn_readfirstlane(tx * TW);
+    };
+    auto fetch = [&](int p) {
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+        const bool live = p < patches;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short *>(x) + (live ? (long long)n * H * W * CIN : 0ll), 0, live ? H * W * CIN * 2 : 0, 0x00020000);
+        const unsigned patch_off = (unsigned)(((y0 - 1) * W + x0 - 1) * (CIN * 2));   // wraps for y0 = 0: outside the resource
+#pragma unroll
+        for (int k = 0; k < BST_PER_THREAD; ++k) {
+            const bool in_row = (unsigned)(st_pp[k] + x0 - 1) < (unsigned)W;
+            stage[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(in_row ? st_off[k] + patch_off : kOOB), 0, 0);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < BST_PER_THREAD; ++k)
+            if (lds_off[k] >= 0) *reinterpret_cast<u32x4 *>(&tile[buf][lds_off[k]]) = stage[k];
+    };
+
+    const int q = lane & 3, wdw = (lane & 31) >> 2;
+    const int lane_off = (q >> 1) * BRS + (2 * wdw + (q & 1)) * BPX + 16 * h;
+    const int prow = 2 * wave;
+    const int base0 = prow * BRS + lane_off, base1 = base0 + 16 * BPX;
+
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    const unsigned row_b = (unsigned)Wo * Cout * 2u, px_b = (unsigned)Cout * 2u;
+    const unsigned out_lane = POOL ? (unsigned)wave * row_b + (unsigned)h * px_b + (unsigned)col * 2u
+                                   : (unsigned)(2 * wave) * row_b + (unsigned)(2 * h) * px_b + (unsigned)col * 2u;
+    const long long y_total = (long long)NB * Ho * Wo * Cout;
+    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], int n, int y0, int x0) {
+        const int u = idx >> 2, gq = idx & 3;
+        const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
+        const long long o_org = n < 0 ? 0ll : (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
+        const long long o_left = n < 0 ? 0ll : (y_total - o_org) * 2;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        const int rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
+        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[r] = acc[u][nt][4 * gq + r] * sc[nt] + sh[nt];
+            if (POOL) {
+                const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
+                const float v = m > 0.f ? m : m * alpha;
+                const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
+                const unsigned off = ok ? out_lane + (unsigned)(8 * u + 2 * gq) * px_b + 64u * nt : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
+                    const int dy = r >> 1, dx = 2 * (8 * u + 2 * gq) + (r & 1);
+                    const bool ok = dy < rows_left && dx < cols_left;
+                    const unsigned off = ok ? out_lane + (unsigned)dy * row_b + (unsigned)dx * px_b + 64u * nt : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[2][NT], prev[2][NT];
+    int pn = -1, py0 = 0, px0 = 0;
+    int p = blockIdx.x;
+    fetch(p);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (; p < patches; p += gridDim.x) {
+        fetch(p + gridDim.x);
+        int n, y0, x0;
+        decode(p, n, y0, x0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
+        const unsigned char *tl = tile[buf];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = (t / 3) * BRS + (t % 3) * BPX;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base0 + toff], 16));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base1 + toff], 16));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[nt][t], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[nt][t], acc[1][nt], 0, 0, 0);
+            }
+            if (t < 8) epi_piece(t, prev, pn, py0, px0);     // epilogue of the previous patch, one piece per tap
+        }
+        store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) prev[u][nt] = acc[u][nt];
+        pn = n; py0 = y0; px0 = x0;
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) epi_piece(idx, prev, pn, py0, px0);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // First layer (Cin = 3, K = 27 -> 28) as a persistent kernel on v_mfma_f32_16x16x4_f32: same arithmetic as
 // conv3x3_c3_kernel (conv_gemm.hip: halo tile in LDS, 7 weight registers per 16 channels, one pool window per
 // lane), but a workgroup walks 16 x 64 pixel patches, fetches the NEXT patch's halo with 16-byte loads into
@@ -236,10 +408,10 @@ constexpr int C3_V4 = 50;                                    // float4 per halo 
 constexpr int C3_ITEMS = (C3_TH + 2) * C3_V4;                // 900
 constexpr int C3_PER_THREAD = (C3_ITEMS + 255) / 256;        // 4
 
-template <bool POOL, int NT>
+template <bool POOL, int NT, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
-                                                          float *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
+                                                          void *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
                                                           int tiles_x, int tiles_y, int patches, long long *stamp) {
     __shared__ __attribute__((aligned(16))) float tile[2][(C3_TH + 2) * C3_ROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,9 +502,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     // M-tile t = (pr, wc): pooled row 2*wave + pr, windows 4*wc + kq.  Stores go through a buffer resource based at
     // the patch's first output element, so a store is one 32-bit offset: lane part + compile-time tile part.
     const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
-    const unsigned row_b = (unsigned)Wo * Cout * 4u, px_b = (unsigned)Cout * 4u;
-    const unsigned lane_off = POOL ? (unsigned)(2 * wave) * row_b + (unsigned)kq * px_b + (unsigned)i16 * 4u
-                                   : (unsigned)(4 * wave) * row_b + (unsigned)(2 * kq) * px_b + (unsigned)i16 * 4u;
+    constexpr unsigned OSZ = OUT_BF16 ? 2u : 4u;            // bytes per output element (bf16 feeds the bf16 network)
+    const unsigned row_b = (unsigned)Wo * Cout * OSZ, px_b = (unsigned)Cout * OSZ;
+    const unsigned lane_off = POOL ? (unsigned)(2 * wave) * row_b + (unsigned)kq * px_b + (unsigned)i16 * OSZ
+                                   : (unsigned)(4 * wave) * row_b + (unsigned)(2 * kq) * px_b + (unsigned)i16 * OSZ;
     const long long y_total = (long long)NB * Ho * Wo * Cout;
 
     // developer stamps (compiled in with -DTY1_DEV_STAMPS only: the fences change the schedule)
@@ -363,9 +536,13 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);
         const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
         const long long o_org = (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
-        const long long o_left = (y_total - o_org) * 4;
+        const long long o_left = (y_total - o_org) * OSZ;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+            static_cast<char *>(y) + o_org * OSZ, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        auto put = [&](float v, unsigned off) {
+            if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+        };
         // output rows / columns of the image left from this lane's first element (a tile is valid below them)
         const int rows_left = Ho - oy0 - (POOL ? 2 : 4) * wave;
         const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * kq;
@@ -412,16 +589,16 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                         const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
                         const float v = m > 0.f ? m : m * alpha;
                         const bool ok = pr < rows_left && 4 * wc < cols_left;
-                        const unsigned off = ok ? lane_off + (unsigned)pr * row_b + (unsigned)(4 * wc) * px_b + 64u * j : kOOB;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+                        const unsigned off = ok ? lane_off + (unsigned)pr * row_b + (unsigned)(4 * wc) * px_b + 16u * OSZ * j : kOOB;
+                        put(v, off);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
                             const int dy = 2 * pr + (r >> 1), dx = 8 * wc + (r & 1);
                             const bool ok = dy < rows_left && dx < cols_left;
-                            const unsigned off = ok ? lane_off + (unsigned)dy * row_b + (unsigned)dx * px_b + 64u * j : kOOB;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+                            const unsigned off = ok ? lane_off + (unsigned)dy * row_b + (unsigned)dx * px_b + 16u * OSZ * j : kOOB;
+                            put(v, off);
                         }
                     }
                 }
@@ -515,28 +692,63 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
 }
 
 
+// Cin == 16 in bf16 (x, w, y bf16; fp32 accumulate), Cout == 32 or 64.
+int conv3x3_c16_direct_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H,
+                            int W, int Cout, int pool, float alpha, hipStream_t s) {
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long long patches = (long long)N * tiles_y * tiles_x;
+    TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c16 bf16): too many patches");
+    const double px = (double)N * H * W;
+    ProfScope prof(pool ? "conv3x3_c16_bf16_pool" : "conv3x3_c16_bf16", s, 2.0 * px * Cout * 144,
+                   2.0 * (px * 16 + 144.0 * Cout + px * Cout / (pool ? 4 : 1)));
+    const int P = (int)patches;
+    const unsigned short *xb = static_cast<const unsigned short *>(x), *wb = static_cast<const unsigned short *>(w);
+    unsigned short *yb = static_cast<unsigned short *>(y);
+#define TY1_C16B(PL, NTV)                                                                                             \
+    do {                                                                                                              \
+        static const int per_cu = resident_blocks(conv3x3_c16_bf16_kernel<PL, NTV>, 4, "TY1_C16B_BLOCKS");            \
+        const long long want = (long long)per_cu * cu_count();                                                        \
+        conv3x3_c16_bf16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(     \
+            xb, wb, scale, shift, yb, N, H, W, Cout, alpha, tiles_x, tiles_y, P);                                     \
+    } while (0)
+    if (Cout == 32) {
+        if (pool) TY1_C16B(true, 1); else TY1_C16B(false, 1);
+    } else {
+        if (pool) TY1_C16B(true, 2); else TY1_C16B(false, 2);
+    }
+#undef TY1_C16B
+    return check_launch("ty1_conv3x3(c16 bf16)");
+}
+
 // Cin == 3, Cout == 16 * NT (NT <= 4), W % 4 == 0, x 16-byte aligned.
-int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, float *y, int N, int H,
-                          int W, int Cout, int pool, float alpha, hipStream_t s) {
+// out_bf16: y is bf16 (the first layer of the bf16 network; the layer itself stays exact f32).
+int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, const float *shift, void *y, int N, int H,
+                          int W, int Cout, int pool, float alpha, int out_bf16, hipStream_t s) {
     const int tiles_x = (W + C3_TW - 1) / C3_TW, tiles_y = (H + C3_TH - 1) / C3_TH;
     const long long patches = (long long)N * tiles_y * tiles_x;
     TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c3): too many patches");
     TY1_REQUIRE((long long)H * W * 12 < (1ll << 31), "ty1_conv3x3(c3): one image must stay below 2 GiB");
     const int P = (int)patches, nt = Cout / 16;
     // persistent grid: as many workgroups as stay resident (30 KB of LDS, <= 128 registers: four per CU)
-#define TY1_C3P(PL, NTV)                                                                                              \
+#define TY1_C3P(PL, NTV, OB)                                                                                          \
     do {                                                                                                              \
-        static const int per_cu = resident_blocks(conv3x3_c3p_kernel<PL, NTV>, 4, "TY1_C3_BLOCKS");                   \
+        static const int per_cu = resident_blocks(conv3x3_c3p_kernel<PL, NTV, OB>, 4, "TY1_C3_BLOCKS");               \
         const long long want = (long long)per_cu * cu_count();                                                        \
         const long long nblk = patches < want ? patches : want;                                                       \
-        conv3x3_c3p_kernel<PL, NTV><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                       \
+        conv3x3_c3p_kernel<PL, NTV, OB><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                   \
             x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr); \
     } while (0)
-    if (pool) {
-        if (nt == 1) TY1_C3P(true, 1); else if (nt == 2) TY1_C3P(true, 2); else if (nt == 3) TY1_C3P(true, 3); else TY1_C3P(true, 4);
+#define TY1_C3P_NT(PL, OB)                                                                                            \
+    do {                                                                                                              \
+        if (nt == 1) TY1_C3P(PL, 1, OB); else if (nt == 2) TY1_C3P(PL, 2, OB);                                        \
+        else if (nt == 3) TY1_C3P(PL, 3, OB); else TY1_C3P(PL, 4, OB);                                                \
+    } while (0)
+    if (out_bf16) {
+        if (pool) TY1_C3P_NT(true, true); else TY1_C3P_NT(false, true);
     } else {
-        if (nt == 1) TY1_C3P(false, 1); else if (nt == 2) TY1_C3P(false, 2); else if (nt == 3) TY1_C3P(false, 3); else TY1_C3P(false, 4);
+        if (pool) TY1_C3P_NT(true, false); else TY1_C3P_NT(false, false);
     }
+#undef TY1_C3P_NT
 #undef TY1_C3P
     return check_launch("ty1_conv3x3(c3)");
 }

@@ -407,9 +407,29 @@ FastDiv make_fastdiv(unsigned d) {
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.M) + n) >> f.l; }
 
+// Element type of the GEMM operands (activations and weights).  A K chunk is always BK*4 bytes of a row (8 or 4
+// 16-byte pieces), so fetch, LDS layout and swizzle do not depend on it; only the fragment -> MFMA step does:
+// a 16-byte LDS read holds 4 floats = the operands of four v_mfma_f32_32x32x2_f32 (k = 2 each, lane half = k
+// parity), or 8 bf16 = the operand of ONE v_mfma_f32_32x32x16_bf16 (lane half = k 8h..8h+7).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+struct OpF32 {
+    static constexpr int ESZ = 4;
+    typedef f32x4v vec;
+};
+struct OpBF16 {
+    static constexpr int ESZ = 2;
+    typedef bf16x8 vec;
+};
+__device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to nearest even (v_cvt_pk_bf16_f32)
+    const __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 struct PersistArgs {
-    const float *x, *w, *scale, *shift;
-    float *y;            // output tensor
+    const void *x, *w;   // activations NHWC and weights OHWI, f32 or bf16
+    const float *scale, *shift;
+    void *y;             // output tensor (f32 or bf16)
     float *part;         // partial tiles of the K-split tail: [split][tail tile][BM][BN]
     int NB, H, W, Cin, Cout, M;
     int chunks_total;
@@ -427,7 +447,9 @@ struct PersistArgs {
     long long *stamp;
 };
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL>
+// BK counts 4-byte units of a row's K chunk (BK * 4 bytes = BKE elements of type OP); OUT_BF16: the fused epilogue
+// stores bf16 (raw partial tiles of the K-split tail are always f32).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL, typename OP = OpF32, bool OUT_BF16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel(const PersistArgs a) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int NTHREADS = 256;
@@ -440,6 +462,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     constexpr int CPR = BK / 4, RPP = NTHREADS / CPR;
     constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
     constexpr int NKB = BK / 8;
+    constexpr int ESZ = OP::ESZ, BKE = BK * 4 / ESZ;       // element size, elements per chunk
+    constexpr int OSZ = OUT_BF16 ? 2 : 4;                  // bytes per output element
     constexpr unsigned kOOB = 0xFFFFFFFFu;
     static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
@@ -457,10 +481,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         a.stamp[(long long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 
-    const int chunks_per_tap = a.Cin / BK;
+    const int chunks_per_tap = a.Cin / BKE;
     const long long x_total = (long long)a.NB * a.H * a.W * a.Cin;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * 4), 0x00020000);
+        const_cast<void *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * ESZ), 0x00020000);
 
     // ---- item descriptors (block-uniform scalars)
     struct Desc {
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         d.kc0 = d.raw ? a.chunks_total * split / a.splits : 0;
         d.kc1 = d.raw ? a.chunks_total * (split + 1) / a.splits : (d.live ? a.chunks_total : 0x7fffffff);
         d.tap0 = (int)fdiv((unsigned)d.kc0, a.d_cpt);
-        d.ci0 = (d.kc0 - d.tap0 * chunks_per_tap) * BK;
+        d.ci0 = (d.kc0 - d.tap0 * chunks_per_tap) * BKE;
         d.pslot = split * a.rem + tail_tile;
         // block-uniform by construction: keep them in scalar registers
         d.mt = __builtin_amdgcn_readfirstlane(d.mt); d.nt = __builtin_amdgcn_readfirstlane(d.nt);
@@ -525,7 +549,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                     xx = rem - yy * a.W;
                 }
                 const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - origin;
-                R.a_base[p] = (unsigned)(el * 4);
+                R.a_base[p] = (unsigned)(el * ESZ);
                 // tap t = 3*(dy+1) + (dx+1) is inside the image: product of a row condition and a column condition
                 const unsigned rows = (yy > 0 ? 0x007u : 0u) | 0x038u | ((int)yy < a.H - 1 ? 0x1C0u : 0u);
                 const unsigned cols = (xx > 0 ? 0x049u : 0u) | 0x092u | ((int)xx < a.W - 1 ? 0x124u : 0u);
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         for (int p = 0; p < BP; ++p) {
             const int n = d.nt * BN + p * RPP + prow;
             R.b_base[p] = (d.live && n < a.Cout && (BP * RPP == BN || p * RPP + prow < BN))
-                              ? (unsigned)((long long)n * 9 * a.Cin * 4) : kOOB;
+                              ? (unsigned)((long long)n * 9 * a.Cin * ESZ) : kOOB;
         }
     };
 
@@ -581,12 +605,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     u32x4 ra[AP], rb[BP];
     int ld_round = 0, ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
     auto load_chunk = [&]() {
-        const long long left = (x_total - org_l) * 4;
+        const long long left = (x_total - org_l) * ESZ;
         const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(a.x + org_l), 0, (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
+            const_cast<char *>(static_cast<const char *>(a.x)) + org_l * ESZ, 0,
+            (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
         const int t3 = ld_tap / 3;
         const int dy = t3 - 1, dx = ld_tap - 3 * t3 - 1;
-        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0 + piece * 4) * 4;   // bytes, may be negative
+        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0) * ESZ + piece * 16;   // bytes, may be negative
         const unsigned tapbit = 1u << ld_tap;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
@@ -604,7 +629,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     // ONE basic block and the scheduler can spread the address arithmetic and the loads between the MFMAs.
     auto advance = [&]() {
         ++ld_kc;
-        ld_ci0 += BK;
+        ld_ci0 += BKE;
         const bool wrap = ld_ci0 == a.Cin;
         ld_ci0 = wrap ? 0 : ld_ci0;
         ld_tap += wrap ? 1 : 0;
@@ -645,42 +670,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     const int a_row0 = wave_m * (32 * WM) + frag_row;
     const int b_row0 = wave_n * (32 * WN) + frag_row;
     const int a_swz = (a_row0 / RB) & (CPR - 1), b_swz = (b_row0 / RB) & (CPR - 1);
+    typedef typename OP::vec fvec;
     struct Frag {
-        float a[WM][4], b[WN][4];
+        fvec a[WM], b[WN];
     };
     auto read_frag = [&](Frag &f, int buf, int kb) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(
+        for (int i = 0; i < WM; ++i)
+            f.a[i] = *reinterpret_cast<const fvec *>(
                 __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + (((kb * 2 + frag_h) ^ a_swz) << 2)], 16));
-            f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
-        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(
+        for (int j = 0; j < WN; ++j)
+            f.b[j] = *reinterpret_cast<const fvec *>(
                 __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + (((kb * 2 + frag_h) ^ b_swz) << 2)], 16));
-            f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
-        }
     };
+    // f32: k0..k1 of the four k pairs a fragment holds.  bf16: the fragment is one MFMA, issued with the first half.
     auto mfma = [&](const Frag &f, int k0, int k1) {
+        if constexpr (ESZ == 4) {
 #pragma unroll
-        for (int k = k0; k < k1; ++k)
+            for (int k = k0; k < k1; ++k)        // k outermost: consecutive MFMAs go to different accumulators
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+        } else {
+            if (k0 == 0) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+            }
+        }
     };
     Frag f0, f1;
     auto zero_f1 = [&]() {
+        const f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j) f1.b[j] = __builtin_bit_cast(fvec, z);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) f1.b[j][k] = 0.f;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) f1.a[i][k] = 0.f;
+        for (int i = 0; i < WM; ++i) f1.a[i] = __builtin_bit_cast(fvec, z);
     };
 
     // per-lane epilogue constants that do not depend on the item (scale / shift depend on nt only)
@@ -750,16 +780,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         } else {
             const int rows_out = POOL ? a.M >> 2 : a.M;
             const int r0 = POOL ? cur.mt * (BM / 4) : cur.mt * BM;
-            const long long obytes = (long long)(rows_out - r0) * a.Cout * 4;
+            const long long obytes = (long long)(rows_out - r0) * a.Cout * OSZ;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                a.y + (long long)r0 * a.Cout, 0, (int)(obytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : obytes), 0x00020000);
-            const unsigned row_bytes = (unsigned)a.Cout * 4u;
+                static_cast<char *>(a.y) + (long long)r0 * a.Cout * OSZ, 0,
+                (int)(obytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : obytes), 0x00020000);
+            const unsigned row_bytes = (unsigned)a.Cout * (unsigned)OSZ;
+            auto put = [&](float v, unsigned off) {
+                if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+            };
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
                 const int n = cur.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
                 const bool n_ok = n < a.Cout;
                 if (POOL) {
-                    const unsigned vb = (unsigned)(wave_m * (8 * WM) + h) * row_bytes + (unsigned)n * 4u;
+                    const unsigned vb = (unsigned)(wave_m * (8 * WM) + h) * row_bytes + (unsigned)n * (unsigned)OSZ;
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -772,10 +807,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                             }
                             const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                             const unsigned off = n_ok ? vb + (unsigned)(8 * i + 2 * g) * row_bytes : kOOB;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pooled), o_rsrc, (int)off, 0, 0);
+                            put(pooled, off);
                         }
                 } else {
-                    const unsigned vb = (unsigned)(wave_m * (32 * WM) + 4 * h) * row_bytes + (unsigned)n * 4u;
+                    const unsigned vb = (unsigned)(wave_m * (32 * WM) + 4 * h) * row_bytes + (unsigned)n * (unsigned)OSZ;
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -783,7 +818,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                             float t = acc[i][j][r] * sc_cur[j] + sh_cur[j];
                             t = t > 0.f ? t : t * a.alpha;
                             const unsigned off = n_ok ? vb + (unsigned)(32 * i + (r & 3) + 8 * (r >> 2)) * row_bytes : kOOB;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), o_rsrc, (int)off, 0, 0);
+                            put(t, off);
                         }
                 }
             }
@@ -818,9 +853,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 // Fix-up of the K-split tail tiles: y = [pool](leaky(sum_s part[s] * scale + shift)).
 // part is [splits][tiles][BM][BN] (tile-local rows, pooled layers in window-major order m = 4*window + q).
 // One block per tile; a thread owns four consecutive channels of one output row (pool: of one window).
-template <int BM, int BN, bool POOL>
+template <int BM, int BN, bool POOL, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict__ part, const float *__restrict__ scale,
-                                                         const float *__restrict__ shift, float *__restrict__ y,
+                                                         const float *__restrict__ shift, void *__restrict__ yv,
                                                          int M, int Cout, int ntiles, int mtiles, int mt_fastest,
                                                          int tile_begin, int tiles, int splits, float alpha) {
     const int tile_local = blockIdx.x;
@@ -828,6 +863,16 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict
     const int mt = mt_fastest ? logical % mtiles : logical / ntiles;
     const int nt = mt_fastest ? logical / mtiles : logical % ntiles;
     constexpr int C4 = BN / 4;
+    auto put4 = [&](size_t el, const float4 &o) {          // four consecutive channels starting at element `el`
+        if constexpr (OUT_BF16) {
+            uint2 pk;
+            pk.x = (unsigned)bf16_bits(o.x) | ((unsigned)bf16_bits(o.y) << 16);
+            pk.y = (unsigned)bf16_bits(o.z) | ((unsigned)bf16_bits(o.w) << 16);
+            *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(yv) + el) = pk;
+        } else {
+            *reinterpret_cast<float4 *>(static_cast<float *>(yv) + el) = o;
+        }
+    };
     const size_t split_stride = (size_t)tiles * BM * BN;
     const float *base = part + (size_t)tile_local * BM * BN;
     // a thread owns four consecutive channels of ONE GEMM row; the slabs are summed with four independent
@@ -875,12 +920,12 @@ __global__ __launch_bounds__(256) void conv_fixup_kernel(const float *__restrict
                 o.x = fmaxf(fmaxf(v.x, v1.x), fmaxf(v2.x, v3.x)); o.y = fmaxf(fmaxf(v.y, v1.y), fmaxf(v2.y, v3.y));
                 o.z = fmaxf(fmaxf(v.z, v1.z), fmaxf(v2.z, v3.z)); o.w = fmaxf(fmaxf(v.w, v1.w), fmaxf(v2.w, v3.w));
                 const int win = mt * (BM / 4) + (r >> 2);
-                if (win * 4 < M) *reinterpret_cast<float4 *>(y + (size_t)win * Cout + n) = o;
+                if (win * 4 < M) put4((size_t)win * Cout + n, o);
             }
             __syncthreads();
         } else if (n < Cout) {
             const int m = mt * BM + r;
-            if (m < M) *reinterpret_cast<float4 *>(y + (size_t)m * Cout + n) = v;
+            if (m < M) put4((size_t)m * Cout + n, v);
         }
     }
 }
@@ -1073,14 +1118,16 @@ int launch_gemm(const char *name, ConvArgs a, int tiles, int splits, double flop
 // One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: one persistent launch over the whole
 // tiles and the K pieces of the tail, then the fix-up of the tail tiles.
 // ws_need != nullptr: size query only (returns the workspace bytes the plan wants).
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL>
+// OP / OUT_BF16: element type of x and w / of y (c.x, c.w, c.y then carry bf16 data behind their float pointers).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL, typename OP = OpF32, bool OUT_BF16 = false>
 int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, size_t *ws_need, hipStream_t s) {
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
+    constexpr int BKE = BK * 4 / OP::ESZ;                    // elements of K per chunk
     PersistArgs a{};
     a.x = c.x; a.w = c.w; a.scale = c.scale; a.shift = c.shift; a.y = c.y; a.part = ws;
     a.NB = c.NB; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.M = c.M;
     a.alpha = c.alpha;
-    a.chunks_total = 9 * c.Cin / BK;
+    a.chunks_total = 9 * c.Cin / BKE;
     a.ntiles = (c.Cout + BN - 1) / BN;
     a.d_img = make_fastdiv(POOL ? (c.H / 2) * (c.W / 2) : c.H * c.W);
     a.d_row = make_fastdiv(POOL ? c.W / 2 : c.W);
@@ -1088,7 +1135,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     a.mtiles = (c.M + BM - 1) / BM;
     a.d_mtiles = make_fastdiv(a.mtiles);
     a.mt_fastest = 0;     // measured (rocprofv3 FETCH_SIZE, batch 64): mt-fastest raised L2 misses 1.5-5x on the deep layers
-    a.d_cpt = make_fastdiv(c.Cin / BK);
+    a.d_cpt = make_fastdiv(c.Cin / BKE);
     const int T = ((c.M + BM - 1) / BM) * a.ntiles;
     TailPlan p = plan_tail(T, a.chunks_total, num_cus());
     const size_t need = (size_t)p.rem * p.splits * BM * BN * sizeof(float);
@@ -1104,7 +1151,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     static const int occ = [] {
         int n = 0;
         static const char *cap = getenv("TY1_MAX_BLOCKS_PER_CU");
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL>,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL, OP, OUT_BF16>,
                                                          64 * WAVES_M * WAVES_N, 0) != hipSuccess || n < 1)
             n = 2;
         if (cap && atoi(cap) > 0 && n > atoi(cap)) n = atoi(cap);
@@ -1116,15 +1163,16 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     const double K = 9.0 * c.Cin, out_rows = POOL ? c.M / 4.0 : (double)c.M;
     char tag[96];
     {
-        snprintf(tag, sizeof tag, "conv_f32_%s%s@%dx%d>%d", name, POOL ? "_pool" : "", c.H, c.Cin, c.Cout);
-        ty1::ProfScope prof(tag, s, 2.0 * c.M * c.Cout * K, 4.0 * ((double)c.M * c.Cin + c.Cout * K + out_rows * c.Cout));
-        conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL><<<grid, 64 * WAVES_M * WAVES_N, 0, s>>>(a);
+        snprintf(tag, sizeof tag, "conv_%s_%s%s@%dx%d>%d", OP::ESZ == 4 ? "f32" : "bf16", name, POOL ? "_pool" : "", c.H, c.Cin, c.Cout);
+        ty1::ProfScope prof(tag, s, 2.0 * c.M * c.Cout * K,
+                            OP::ESZ * ((double)c.M * c.Cin + c.Cout * K) + (OUT_BF16 ? 2.0 : 4.0) * out_rows * c.Cout);
+        conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL, OP, OUT_BF16><<<grid, 64 * WAVES_M * WAVES_N, 0, s>>>(a);
         if (int rc = ty1::check_launch(name)) return rc;
     }
     if (p.rem) {
         snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", c.H, c.Cin, c.Cout);
         ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
-        conv_fixup_kernel<BM, BN, POOL><<<dim3(p.rem, BM * BN / 4 / 256 < 32 ? BM * BN / 4 / 256 : 32), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
+        conv_fixup_kernel<BM, BN, POOL, OUT_BF16><<<dim3(p.rem, BM * BN / 4 / 256 < 32 ? BM * BN / 4 / 256 : 32), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
                                                                        p.rem, p.splits, c.alpha);
         return ty1::check_launch("conv_fixup");
     }
@@ -1160,7 +1208,7 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
         static const char *old_c3 = getenv("TY1_OLD_C3");             // developer override
         // (the persistent kernel pools before it activates, which needs a non-decreasing LeakyReLU: alpha >= 0)
         if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && alpha >= 0.f && !old_c3)
-            return ty1::conv3x3_c3_persistent(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
+            return ty1::conv3x3_c3_persistent(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, 0, s);
         if (pool)
             launch_c3<true>(Cout / 16, grid, s, x, w, scale, shift, y, N, H, W, Cout, alpha);
         else
@@ -1207,7 +1255,96 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     return ty1::fail("ty1_conv3x3: Cout=%d must be a multiple of 32 when Cin != 3", Cout);
 }
 
+// bf16 network: activations and weights bf16, fp32 accumulate, folded BN in fp32.  out_f32 (pool == 0 only): the
+// layer stores fp32 (the last conv layer feeds the fp32 Dense).  Cin == 3: x and w are fp32 (the image enters in
+// fp32 and the first layer stays exact), y is bf16.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+int run_conv_bf16(const char *name, bool pool, bool out_f32, const ConvArgs &a, float *ws, size_t ws_bytes, size_t *ws_need,
+                  hipStream_t s) {
+    if (pool) return run_conv<WM, WN, WAVES_M, WAVES_N, BK, true, OpBF16, true>(name, a, ws, ws_bytes, ws_need, s);
+    if (out_f32) return run_conv<WM, WN, WAVES_M, WAVES_N, BK, false, OpBF16, false>(name, a, ws, ws_bytes, ws_need, s);
+    return run_conv<WM, WN, WAVES_M, WAVES_N, BK, false, OpBF16, true>(name, a, ws, ws_bytes, ws_need, s);
+}
+
+int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
+                          int Cin, int Cout, int pool, float alpha, int out_f32, float *ws, size_t ws_bytes, size_t *ws_need,
+                          hipStream_t s) {
+    TY1_REQUIRE(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ty1_conv3x3_bf16: bad dimensions");
+    if (ws_need) *ws_need = 0;
+    if (N == 0) return 0;
+    TY1_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0), "ty1_conv3x3_bf16: pool needs even H, W (got %dx%d)", H, W);
+    TY1_REQUIRE(Cout % 16 == 0, "ty1_conv3x3_bf16: Cout=%d must be a multiple of 16", Cout);
+    TY1_REQUIRE((long long)N * H * W < (1ll << 31) - 256, "ty1_conv3x3_bf16: N*H*W must be below 2^31");
+    TY1_REQUIRE(alpha >= 0.f, "ty1_conv3x3_bf16: alpha must be >= 0");
+    TY1_REQUIRE(!out_f32 || !pool, "ty1_conv3x3_bf16: fp32 output is supported for pool == 0 only");
+    if (!ws_need) {
+        TY1_REQUIRE(x && w && scale && shift && y, "ty1_conv3x3_bf16: null pointer");
+        TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)y & 7) == 0,
+                    "ty1_conv3x3_bf16: x, w and workspace must be 16-byte aligned, y 8-byte aligned");
+    }
+    if (Cin == 3) {
+        TY1_REQUIRE(Cout <= 64 && W % 4 == 0 && (long long)H * W * 12 < (1ll << 31) && !out_f32,
+                    "ty1_conv3x3_bf16: Cin=3 needs Cout <= 64, W %% 4 == 0, bf16 output");
+        if (ws_need) return 0;
+        const double px = (double)N * H * W;
+        ty1::ProfScope prof(pool ? "conv3x3_c3_pool_bf16out" : "conv3x3_c3_bf16out", s, 2.0 * px * Cout * 27,
+                            4.0 * (px * 3 + 27.0 * Cout) + 2.0 * px * Cout / (pool ? 4 : 1));
+        return ty1::conv3x3_c3_persistent(static_cast<const float *>(x), static_cast<const float *>(w), scale, shift, y, N, H, W,
+                                          Cout, pool, alpha, 1, s);
+    }
+    if (Cin == 16) {
+        TY1_REQUIRE((Cout == 32 || Cout == 64) && (long long)H * W * 32 < (1ll << 31) && !out_f32,
+                    "ty1_conv3x3_bf16: Cin=16 needs Cout 32 or 64, bf16 output");
+        if (ws_need) return 0;
+        return ty1::conv3x3_c16_direct_bf16(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
+    }
+    TY1_REQUIRE(Cin % 32 == 0, "ty1_conv3x3_bf16: Cin=%d must be 3, 16 or a multiple of 32", Cin);
+    ConvArgs a{};
+    a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w); a.scale = scale; a.shift = shift;
+    a.y = static_cast<float *>(y);
+    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = 9 * Cin; a.ldy = Cout;
+    a.M = N * H * W;
+    a.alpha = alpha;
+    const bool p = pool != 0, of = out_f32 != 0;
+    if (Cin % 64 != 0) {               // 64-byte K chunks (32 bf16)
+        TY1_REQUIRE(Cout % 64 == 0, "ty1_conv3x3_bf16: Cin=%d needs Cout %% 64 == 0 (got %d)", Cin, Cout);
+        return run_conv_bf16<2, 1, 2, 2, 16>("bk16_128x64", p, of, a, ws, ws_bytes, ws_need, s);
+    }
+    const long long mt128 = ((long long)a.M + 127) / 128;
+    if (Cout % 128 == 0 && mt128 * (Cout / 128) >= 2 * num_cus())
+        return run_conv_bf16<2, 2, 2, 2, 32>("128x128", p, of, a, ws, ws_bytes, ws_need, s);
+    TY1_REQUIRE(Cout % 64 == 0, "ty1_conv3x3_bf16: Cout=%d must be a multiple of 64 when Cin >= 32", Cout);
+    if (mt128 * (Cout / 64) >= 2 * num_cus() || a.M >= 4096 * 2)
+        return run_conv_bf16<2, 1, 2, 2, 32>("128x64", p, of, a, ws, ws_bytes, ws_need, s);
+    return run_conv_bf16<1, 1, 2, 2, 32>("64x64", p, of, a, ws, ws_bytes, ws_need, s);
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += 256ll * gridDim.x) y[i] = bf16_bits(x[i]);
+}
+
 }  // namespace
+
+extern "C" int ty1_conv3x3_workspace_bytes_bf16(int N, int H, int W, int Cin, int Cout, int pool, size_t *bytes) {
+    TY1_REQUIRE(bytes, "ty1_conv3x3_workspace_bytes_bf16: null result pointer");
+    return conv3x3_dispatch_bf16(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, pool, 0.f, 0, nullptr, 0, bytes, nullptr);
+}
+
+extern "C" int ty1_conv3x3_bn_leaky_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N,
+                                         int H, int W, int Cin, int Cout, int pool, float alpha, int out_f32, void *workspace,
+                                         size_t workspace_bytes, ty1_stream_t stream) {
+    return conv3x3_dispatch_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, out_f32, (float *)workspace,
+                                 workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ty1_cast_f32_to_bf16(const float *x, void *y, long long n, ty1_stream_t stream) {
+    TY1_REQUIRE(n >= 0, "ty1_cast_f32_to_bf16: bad length");
+    if (n == 0) return 0;
+    TY1_REQUIRE(x && y, "ty1_cast_f32_to_bf16: null pointer");
+    const long long blocks = (n + 255) / 256;
+    cast_f32_bf16_kernel<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, (hipStream_t)stream>>>(x, static_cast<unsigned short *>(y), n);
+    return ty1::check_launch("ty1_cast_f32_to_bf16");
+}
 
 extern "C" int ty1_debug_stamp_buffer(long long *buf, long long cap_blocks) {
     g_stamp = buf;

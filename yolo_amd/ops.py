@@ -66,6 +66,51 @@ def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None, workspa
     return out
 
 
+def conv3x3_workspace_bytes_bf16(N, H, W, Cin, Cout, pool):
+    """Scratch bytes ty1_conv3x3_bn_leaky_bf16 wants for this problem."""
+    import ctypes
+    n = ctypes.c_size_t(0)
+    _lib.call('ty1_conv3x3_workspace_bytes_bf16', N, H, W, Cin, Cout, int(bool(pool)), ctypes.addressof(n))
+    return int(n.value)
+
+
+def cast_bf16(x, out=None):
+    """f32 device tensor -> bf16 (round to nearest even) with the library's own kernel."""
+    _chk(x, torch.float32, 'x')
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    else:
+        _chk(out, torch.bfloat16, 'out')
+        assert out.shape == x.shape
+    _lib.call('ty1_cast_f32_to_bf16', x.data_ptr(), out.data_ptr(), x.numel(), _lib.current_stream())
+    return out
+
+
+def conv3x3_bn_leaky_bf16(x, w_ohwi, scale, shift, pool, alpha=0.1, out_f32=False, out=None, workspace=None):
+    """The conv block of the bf16 network.  Cin == 3: x and w are f32 (first layer), otherwise bf16; the result is
+    bf16, or f32 with out_f32 (unpooled layers only).  fp32 accumulation and epilogue."""
+    N, H, W, Cin = x.shape
+    in_dt = torch.float32 if Cin == 3 else torch.bfloat16
+    _chk(x, in_dt, 'x'); _chk(w_ohwi, in_dt, 'w')
+    _chk(scale, torch.float32, 'scale'); _chk(shift, torch.float32, 'shift')
+    Cout = w_ohwi.shape[0]
+    assert tuple(w_ohwi.shape) == (Cout, 3, 3, Cin), w_ohwi.shape
+    oshape = (N, H // 2, W // 2, Cout) if pool else (N, H, W, Cout)
+    out_dt = torch.float32 if out_f32 else torch.bfloat16
+    if out is None:
+        out = torch.empty(oshape, dtype=out_dt, device=x.device)
+    else:
+        _chk(out, out_dt, 'out')
+        assert tuple(out.shape) == oshape
+    if workspace is not None and (not workspace.is_cuda or not workspace.is_contiguous()):
+        raise ValueError('workspace must be a contiguous tensor on the GPU')
+    _lib.call('ty1_conv3x3_bn_leaky_bf16', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), int(bool(out_f32)),
+              workspace.data_ptr() if workspace is not None else None,
+              workspace.numel() * workspace.element_size() if workspace is not None else 0, _lib.current_stream())
+    return out
+
+
 def pick_splits(K, n_rows, units, slots=512):
     """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills whole rounds of
     `slots` resident blocks (2 per CU), with at least 4 chunks of 32 per slice."""
