@@ -36,13 +36,26 @@ def conv_block_ref(x_nchw, w_hwio, gamma, beta, mean, var, pool):
     return y
 
 
-def backbone_ref(x_nhwc, params, return_all=False):
-    """x (N,448,448,3) f32 NHWC -> (N,12544) flattened in HWC order."""
+def _bf16(t):
+    """round to the nearest bf16 (ties to even), kept in fp32"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def backbone_ref(x_nhwc, params, return_all=False, bf16=False):
+    """x (N,448,448,3) f32 NHWC -> (N,12544) flattened in HWC order.
+    bf16=True restates the build's bf16 network (BASELINE config 3; the reference itself is fp32 only): weights of
+    layers 1.. and the activations between layers are rounded to bf16, everything is accumulated in fp32, the last
+    layer's output stays fp32."""
     x = torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
     acts = []
     for i in range(N_CONV):
-        x = conv_block_ref(x, params[f'conv{i}_w'], params[f'bn{i}_gamma'], params[f'bn{i}_beta'],
+        w = params[f'conv{i}_w']
+        if bf16 and i > 0:
+            w = _bf16(torch.from_numpy(np.ascontiguousarray(w, np.float32))).numpy()
+        x = conv_block_ref(x, w, params[f'bn{i}_gamma'], params[f'bn{i}_beta'],
                            params[f'bn{i}_mean'], params[f'bn{i}_var'], pool=i < N_POOL)
+        if bf16 and i < N_CONV - 1:
+            x = _bf16(x)
         if return_all:
             acts.append(x.permute(0, 2, 3, 1).contiguous().numpy())
     flat = x.permute(0, 2, 3, 1).contiguous().reshape(x.shape[0], -1)
@@ -65,8 +78,8 @@ def head_activate_ref(z, S=7, B=2, C=20):
     return torch.cat([cls, conf, box], dim=-1).numpy()
 
 
-def model_ref(x_nhwc, params, S=7, B=2, C=20):
-    feats = backbone_ref(x_nhwc, params)
+def model_ref(x_nhwc, params, S=7, B=2, C=20, bf16=False):
+    feats = backbone_ref(x_nhwc, params, bf16=bf16)
     z = dense_ref(feats, params['dense_w'], params['dense_b'])
     return head_activate_ref(z, S, B, C)
 

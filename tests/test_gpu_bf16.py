@@ -93,3 +93,44 @@ def test_bf16_rejects_what_it_does_not_support():
         ops.conv3x3_bn_leaky_bf16(x, w, s, s, True, out_f32=True)
     with pytest.raises(Exception, match='alpha'):
         ops.conv3x3_bn_leaky_bf16(x, w, s, s, False, alpha=-0.1)
+
+
+# ------------------------------------------------------------------------------- whole model in bf16
+@pytest.mark.parametrize('dense_init', ['spread', 'glorot'])
+def test_model_bf16_end_to_end(dense_init):
+    """Whole network with dtype='bf16' against (a) the oracle restating the same bf16 rounding points and (b) the
+    fp32 oracle of the reference.  Stated bf16 tolerances (measured values are printed with -s):
+      per-layer activations: within 2 % of the layer's largest magnitude of (a)   [measured 0.2-0.7 %];
+      Dense logits: within 3 % of their RMS of (a), 6 % of (b)          [measured 0.8-1.0 % and 2.4-2.5 %];
+      head outputs (probabilities, logit RMS 9 with glorot and 39 with 'spread' Dense weights under random BN):
+      within 0.08 of (b) for glorot, 0.25 for 'spread'                  [measured 0.034 and 0.11].
+    Detections: bit-exact given the GPU's own scores."""
+    import oracle
+    from yolo_amd.engine import DeviceModel
+    N = 2
+    prm = P.make_random_params(seed=1, C=20, dense_init=dense_init, bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(0)).numpy()
+    model = DeviceModel(prm, C=20, device=DEV, dtype='bf16')
+    xd = dev(x)
+    y = model.predict(xd).cpu().numpy()
+    ws = model.workspace(N)
+    z = ws['part'].sum(0)[:, :model.units].cpu().numpy() + prm['dense_b']
+    feats_a, acts_a = model_ref.backbone_ref(x, prm, return_all=True, bf16=True)
+    for i, (a_got, a_ref) in enumerate(zip(ws['acts'], acts_a)):
+        g = a_got.float().cpu().numpy()
+        err = np.abs(g - a_ref).max() / max(1.0, np.abs(a_ref).max())
+        print(f'layer {i}: max err / max |ref| = {err:.2e}')
+        assert err < 2e-2
+    z_a = model_ref.dense_ref(feats_a, prm['dense_w'], prm['dense_b'])
+    z_b = model_ref.dense_ref(model_ref.backbone_ref(x, prm), prm['dense_w'], prm['dense_b'])
+    rms = float(np.sqrt((z_b ** 2).mean()))
+    ea, eb = np.abs(z - z_a).max() / rms, np.abs(z - z_b).max() / rms
+    print(f'logit rms {rms:.3f}: max err vs bf16 oracle {ea:.3e} rms, vs fp32 oracle {eb:.3e} rms')
+    assert ea < 3e-2 and eb < 6e-2
+    y_b = model_ref.model_ref(x, prm, 7, 2, 20)
+    print('head outputs vs fp32 oracle', np.abs(y - y_b).max())
+    assert np.abs(y - y_b).max() < (0.08 if dense_init == 'glorot' else 0.25)
+    boxes, score, cls, keep = (t.cpu().numpy() for t in model.detect(xd))
+    want = oracle.decode_nms(y, 2, 20, 448)
+    assert np.array_equal(keep, want['keep']) and np.array_equal(cls, want['cls'])
+    assert np.array_equal(boxes.view(np.uint64), np.ascontiguousarray(want['boxes']).view(np.uint64))

@@ -2,6 +2,7 @@
 """Auxiliary measurements for the other BASELINE.json configs (not the contract line of bench.py):
   --train    configs[3]: one VOC-20 training step (frozen backbone fwd + yolo_loss fwd/bwd + Dense wgrad + SUM
              all-reduce + Adam), batch 32 per GPU; launch with torch.distributed.run for N > 1
+  --bf16     configs[2]: bf16 inference incl. decode+NMS, 128 images per GPU (1024 over 8), weak scaling, no collective
   --nms      configs[4]: decode + threshold + NMS stress, C=1 head, batch 4096, dense candidates
 """
 import argparse, json, os, sys, time
@@ -14,6 +15,8 @@ from yolo_amd.engine import DeviceModel, Trainer  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--train', action='store_true')
 ap.add_argument('--nms', action='store_true')
+ap.add_argument('--bf16', action='store_true')
+ap.add_argument('--bf16-batch', type=int, default=128)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--batch', type=int, default=32)
 args = ap.parse_args()
@@ -53,6 +56,32 @@ if args.train:
         print(json.dumps({'config': 'configs[3] training step', 'n_gpus': world, 'batch_per_gpu': N, 'ms_per_step': round(1e3 * dt / args.steps, 3),
                           'images_per_sec': round(world * N * args.steps / dt, 1), 'loss': float(loss.item()),
                           'kernels_us': {k: round(1e3 * v['ms'] / max(v['launches'], 1), 1) for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms'])}}))
+if args.bf16:
+    N, C = args.bf16_batch, 20
+    prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')
+    model = DeviceModel(prm, C=C, device=dev, dtype='bf16')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(rank)).to(dev)
+    for _ in range(3):
+        det = model.detect(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det = model.detect(x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    with ops.KernelTimer() as kt:
+        for _ in range(5):
+            model.detect(x)
+        torch.cuda.synchronize()
+        table = kt.table()
+    if rank == 0:
+        print(json.dumps({'config': 'configs[2] bf16 inference incl. decode+NMS', 'n_gpus': world, 'batch_per_gpu': N,
+                          'ms_per_step': round(1e3 * dt / args.steps, 3), 'images_per_sec': round(world * N * args.steps / dt, 1),
+                          'kept_per_image': float(det[3].sum().item()) / N,
+                          'kernels_us_tflops': {k: [round(1e3 * v['ms'] / max(v['launches'], 1), 1), round(v['flops'] / max(v['ms'], 1e-9) / 1e9, 1)]
+                                                for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms'])}}))
 if args.nms:
     N, C = 4096, 1
     rng = np.random.default_rng(2)

@@ -12,7 +12,13 @@ from .params import CONV_CHANNELS, N_POOL, BN_EPS, LEAKY_ALPHA, hwio_to_ohwi, de
 
 
 class DeviceModel:
-    def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0', conv_specs=None):
+    def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0', conv_specs=None, dtype='f32'):
+        """dtype 'f32': the reference's arithmetic.  dtype 'bf16' (BASELINE config 3): conv activations and
+        weights of layers 1.. in bf16 with fp32 accumulation; the image, the first layer's weights, BN, the last
+        conv layer's output, Dense, head and decode/NMS stay fp32."""
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
+        self.dtype = dtype
         self.S, self.B, self.C, self.img_size = S, B, C, img_size
         self.device = torch.device(device)
         self.units = S * S * (C + 5 * B)
@@ -22,8 +28,11 @@ class DeviceModel:
         for i, (cin, cout, pool) in enumerate(self.specs):
             scale, shift = ops.fold_bn(params[f'bn{i}_gamma'], params[f'bn{i}_beta'], params[f'bn{i}_mean'],
                                        params[f'bn{i}_var'], BN_EPS)
+            w = torch.from_numpy(hwio_to_ohwi(params[f'conv{i}_w'])).to(self.device)
+            if dtype == 'bf16' and cin != 3:
+                w = ops.cast_bf16(w)
             self.conv.append(dict(
-                w=torch.from_numpy(hwio_to_ohwi(params[f'conv{i}_w'])).to(self.device),
+                w=w,
                 scale=torch.from_numpy(scale).to(self.device), shift=torch.from_numpy(shift).to(self.device),
                 pool=pool))
         assert params['dense_w'].shape[1] == self.units, (params['dense_w'].shape, self.units)
@@ -38,11 +47,14 @@ class DeviceModel:
         if ws is None:
             dev, f32 = self.device, torch.float32
             acts, h, scratch = [], self.img_size, 0
-            for cin, cout, pool in self.specs:
-                scratch = max(scratch, ops.conv3x3_workspace_bytes(N, h, h, cin, cout, pool))
+            bf = self.dtype == 'bf16'
+            for i, (cin, cout, pool) in enumerate(self.specs):
+                need = ops.conv3x3_workspace_bytes_bf16 if bf else ops.conv3x3_workspace_bytes
+                scratch = max(scratch, need(N, h, h, cin, cout, pool))
                 if pool:
                     h //= 2
-                acts.append(torch.empty((N, h, h, cout), dtype=f32, device=dev))
+                last = i == len(self.specs) - 1
+                acts.append(torch.empty((N, h, h, cout), dtype=torch.bfloat16 if bf and not last else f32, device=dev))
             splits = ops.pick_splits(self.K, N, self.units)
             ldz = ops.round_up(self.units, 4)
             slots = self.S * self.S * self.B
@@ -59,9 +71,13 @@ class DeviceModel:
     def backbone(self, x, ws=None):
         """x (N,H,W,3) f32 NHWC on the device -> features (N, 12544) (HWC flatten)."""
         ws = ws or self.workspace(x.shape[0])
-        for layer, out in zip(self.conv, ws['acts']):
-            x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out,
-                                     workspace=ws['scratch'])
+        for i, (layer, out) in enumerate(zip(self.conv, ws['acts'])):
+            if self.dtype == 'bf16':
+                x = ops.conv3x3_bn_leaky_bf16(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA,
+                                              out_f32=i == len(self.conv) - 1, out=out, workspace=ws['scratch'])
+            else:
+                x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out,
+                                         workspace=ws['scratch'])
         return x.reshape(x.shape[0], -1)
 
     def head(self, feats, ws=None):
