@@ -90,6 +90,17 @@ int ty1_conv3x3_bn_leaky_bf16(const void *x, const void *w, const float *scale, 
 int ty1_cast_f32_to_bf16(const float *x, void *y, long long n, ty1_stream_t stream);
 
 /*
+ * Preprocessing of one decoded image on the GPU: uint8 (H0,W0,3) HWC -> cv2.resize INTER_LINEAR to (out_h,out_w)
+ * -> optional channel swap (cv2.cvtColor BGR2RGB when the decoder delivered BGR) -> / 255 -> fp32 (out_h,out_w,3),
+ * i.e. one image slot of the network's NHWC input batch.
+ * Replaces /root/reference/utils.py:11-15 (cvtColor, resize, image / 255.); file decoding stays on the host.
+ * Parity unpinned: OpenCV is absent, the kernel follows the published 8-bit INTER_LINEAR definition as restated in
+ * yolo_amd/utils.py:resize_bilinear_u8 and is bit-identical to that restatement.
+ */
+int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int swap_rb, float *out, int out_h, int out_w,
+                      ty1_stream_t stream);
+
+/*
  * Split-K Dense: part[s][n][u] = sum_{k in slice s} x[n][k] * wt[u][k]      (no bias here)
  * Replaces the matmul of Flatten + Dense(1470,'linear',name='connected_0'):
  * /root/reference/models/model_tiny_yolov1.py:89,96.  The bias add and the split-K reduction

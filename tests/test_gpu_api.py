@@ -196,3 +196,39 @@ def test_detection_records_roundtrip_on_device():
     boxes, score, cls, keep = parallel.unpack_detections(parallel.gather_detections(rec))
     assert torch.equal(boxes, det[0]) and torch.equal(keep, det[3]) and torch.equal(score, det[1])
     assert torch.equal(cls[keep.bool()], det[2][keep.bool()])
+
+
+# ------------------------------------------------------------------------------- preprocessing on the GPU (8f row 2)
+@pytest.mark.parametrize('h0,w0', [(448, 448), (375, 500), (37, 1000), (1080, 1920), (2, 3), (449, 447)])
+def test_preprocess_u8_equals_host_restatement(h0, w0):
+    """ty1_preprocess_u8 against yolo_amd.utils.resize_bilinear_u8 (the stated cv2 INTER_LINEAR 8-bit definition;
+    parity unpinned: OpenCV is not installed) followed by the reference's `image / 255.` in float64: bit-exact."""
+    from yolo_amd import ops
+    from yolo_amd.utils import resize_bilinear_u8
+    img = np.random.default_rng(h0 + w0).integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+    want = (resize_bilinear_u8(img, 448, 448) / 255.).astype(np.float32)
+    d = torch.from_numpy(img).to(DEV)
+    got = ops.preprocess_u8(d, (448, 448)).cpu().numpy()
+    assert np.array_equal(got, want)
+    got_swapped = ops.preprocess_u8(d, (448, 448), swap_rb=True).cpu().numpy()
+    assert np.array_equal(got_swapped, want[..., ::-1])
+    # into one slot of a batch, other output size
+    batch = torch.zeros((3, 224, 224, 3), device=DEV)
+    ops.preprocess_u8(d, (224, 224), out=batch[1])
+    assert np.array_equal(batch[1].cpu().numpy(), (resize_bilinear_u8(img, 224, 224) / 255.).astype(np.float32))
+    assert not batch[0].any() and not batch[2].any()
+
+
+def test_detect_from_file_uses_device_preprocessing(tmp_path):
+    from PIL import Image
+    from yolo_amd.tiny_yolov1 import TinyYOLOv1
+    from yolo_amd.utils import load_img
+    img = np.random.default_rng(9).integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    path = str(tmp_path / 'a.png')
+    Image.fromarray(img).save(path)
+    det = TinyYOLOv1(input_path=path, device=DEV)
+    from_file = det.detect()
+    host_img, _, _ = load_img(path, (448, 448, 3))
+    from_array = det.detect(host_img)
+    assert len(from_file) == 1 and np.array_equal(from_file[0]['slots'], from_array[0]['slots'])
+    assert np.array_equal(from_file[0]['boxes'], from_array[0]['boxes'])

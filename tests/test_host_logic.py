@@ -132,3 +132,50 @@ def test_shard_bounds_cover_the_batch():
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ------------------------------------------------------------------------------- next rows: labels, consumer
+def test_label_encoder_vs_reference_goldens():
+    """tests/golden/labels_*.npz were written by the reference's own SequenceData.read / SequenceForAirplanes.read
+    (tests/golden/make_golden_labels.py): bit-exact."""
+    from conftest import load_golden
+    from yolo_amd.data_sequence import encode_boxes, parse_annotation_line
+    g = load_golden('labels_c20.npz')
+    for line, (h, w), want in zip(g['lines'], g['hw'], g['label_matrix']):
+        _, boxes = parse_annotation_line(str(line))
+        got = encode_boxes(boxes, int(h), int(w), 7, 20)
+        assert got.dtype == np.float64 and np.array_equal(got, want)
+    g = load_golden('labels_c1.npz')
+    for i, ((h, w), want) in enumerate(zip(g['hw'], g['label_matrix'])):
+        boxes = g['boxes'][g['box_off'][i]:g['box_off'][i + 1]]
+        assert np.array_equal(encode_boxes(boxes, int(h), int(w), 7, 1), want)
+
+
+def test_sequence_data_protocol(tmp_path):
+    from PIL import Image
+    from yolo_amd.data_sequence import SequenceData
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 256, (30 + i, 40, 3), dtype=np.uint8)).save(str(tmp_path / f'{i}.png'))
+        lines.append(f'{tmp_path}/{i}.png 4,5,20,25,{i} 10,10,30,{29 + i},7\n')
+    (tmp_path / '2007_train.txt').write_text(''.join(lines))
+    seq = SequenceData('train', str(tmp_path), (448, 448, 3), 2, shuffle=False)
+    assert len(seq) == 3
+    X, y = seq[0]
+    assert X.shape == (2, 448, 448, 3) and y.shape == (2, 7, 7, 25) and y[..., 24].sum() == 4
+    X, y = seq[2]
+    assert X.shape[0] == 1
+    seq.on_epoch_end()
+
+
+def test_detection_records():
+    from yolo_amd.detections import to_records, voc_result_lines
+    boxes = np.array([[10.9, 20.2, 100.7, 200.99], [0, 0, 1, 1], [-3.5, 5.5, 447.9, 448.0]])
+    recs = to_records(boxes, np.array([0.9, 0.1, 0.5], np.float32), np.array([14, 3, 6]), np.array([1, 0, 1], np.uint8),
+                      image_hw=(224, 896))
+    assert [r['slot'] for r in recs] == [0, 2] and [r['name'] for r in recs] == ['person', 'car']
+    assert recs[0]['corners'] == (10, 20, 100, 200) and recs[1]['corners'] == (-3, 5, 447, 448)     # int() truncates toward 0
+    assert recs[0]['box'] == (10.9 * 2, 20.2 * 0.5, 100.7 * 2, 200.99 * 0.5)
+    lines = voc_result_lines('000012', recs)
+    assert lines['person'] == ['000012 0.900000 21.8 10.1 201.4 100.5']

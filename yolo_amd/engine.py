@@ -105,6 +105,8 @@ class Trainer:
     (Keras defaults) updates the only trainable parameters: the Dense kernel and bias (Q8)."""
 
     def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None):
+        if model.dtype != 'f32':
+            raise ValueError("training runs in fp32 (the reference's arithmetic): build the model with dtype='f32'")
         self.model, self.group = model, group
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
         dev = model.device

@@ -105,12 +105,13 @@ def _chain(outputs):
 class Model:
     """Model(inputs=..., outputs=...) for the tiny-YOLOv1 pattern."""
 
-    def __init__(self, inputs, outputs, device='cuda:0', seed=1):
+    def __init__(self, inputs, outputs, device='cuda:0', seed=1, dtype='f32'):
+        """dtype='bf16' runs inference with bf16 conv activations/weights (engine.DeviceModel); training needs 'f32'."""
         root, layers = _chain(outputs)
         if root is not inputs:
             raise ValueError('outputs are not derived from inputs')
         self.inputs, self.outputs, self.layers = inputs, outputs, layers
-        self.device = device
+        self.device, self.dtype = device, dtype
         self._parse(layers)
         self.params = self._init_params(seed)
         self._engine = None
@@ -234,7 +235,8 @@ class Model:
     def engine(self):
         if self._engine is None:
             from .engine import DeviceModel
-            self._engine = DeviceModel(self.params, self.S, self.B, self.C, self.img_size, self.device, self.conv_specs)
+            self._engine = DeviceModel(self.params, self.S, self.B, self.C, self.img_size, self.device, self.conv_specs,
+                                       dtype=self.dtype)
         return self._engine
 
     def _to_device(self, x):

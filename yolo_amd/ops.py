@@ -111,6 +111,22 @@ def conv3x3_bn_leaky_bf16(x, w_ohwi, scale, shift, pool, alpha=0.1, out_f32=Fals
     return out
 
 
+def preprocess_u8(img_u8, out_hw=(448, 448), swap_rb=False, out=None):
+    """uint8 (H0,W0,3) image on the device -> fp32 (out_h,out_w,3) in [0,1]: cv2.resize INTER_LINEAR + /255
+    (utils.py:11-15).  `out` may be one slot x[n] of the network's input batch."""
+    _chk(img_u8, torch.uint8, 'img')
+    H0, W0, c = img_u8.shape
+    assert c == 3
+    if out is None:
+        out = torch.empty((out_hw[0], out_hw[1], 3), dtype=torch.float32, device=img_u8.device)
+    else:
+        _chk(out, torch.float32, 'out')
+        assert tuple(out.shape) == (out_hw[0], out_hw[1], 3)
+    _lib.call('ty1_preprocess_u8', img_u8.data_ptr(), H0, W0, int(bool(swap_rb)), out.data_ptr(), out_hw[0], out_hw[1],
+              _lib.current_stream())
+    return out
+
+
 def pick_splits(K, n_rows, units, slots=512):
     """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills whole rounds of
     `slots` resident blocks (2 per CU), with at least 4 chunks of 32 per slice."""

@@ -8,7 +8,7 @@ import torch
 from . import ops
 from .keras_facade import Model
 from .models.model_tiny_yolov1 import model_tiny_YOLOv1
-from .utils import load_img, X_Y_W_H_To_Min_Max  # noqa: F401
+from .utils import load_img, load_img_device, X_Y_W_H_To_Min_Max  # noqa: F401
 
 classes_name = ['aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow', 'diningtable',
                 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train', 'tvmonitor']
@@ -39,8 +39,10 @@ class TinyYOLOv1(object):
         Returns a list (one entry per image) of dicts with `boxes` (k,4) float64 pixels in the
         448x448 frame, `corners` (k,4) int (the reference's int() truncation), `classes`, `names`,
         `scores`, in the reference's raster order."""
-        if image is None:
-            image, _, _ = load_img(path=self.input_path, shape=self.inputs.shape[1:])
+        if image is None or isinstance(image, str):
+            # file -> host decode -> uint8 upload -> resize + /255 on the GPU (same pixels as load_img, fp32)
+            x, _, _ = load_img_device(image or self.input_path, tuple(self.inputs.shape[1:]), self.model.device)
+            image = x[None]
         if isinstance(image, np.ndarray) and image.ndim == 3:
             image = image[None]
         x = self.model._to_device(image)

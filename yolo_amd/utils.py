@@ -27,6 +27,23 @@ def load_img(path, shape=(448, 448, 3)):
     return image, image_h, image_w
 
 
+def load_img_device(path_or_array, shape=(448, 448, 3), device='cuda:0', out=None, bgr=False):
+    """load_img with the resize and normalisation on the GPU (ty1_preprocess_u8): decode on the host (PIL) or take a
+    decoded uint8 HxWx3 array, upload the uint8 pixels (3 bytes per source pixel instead of 12 per output pixel),
+    resize + /255 into `out` (e.g. one slot of the input batch).  -> (fp32 (H,W,3) device tensor, image_h, image_w);
+    equals np.float32(load_img(...)[0]) bit for bit."""
+    import torch
+    from . import ops
+    if isinstance(path_or_array, str):
+        from PIL import Image
+        image = np.array(Image.open(path_or_array).convert('RGB'))      # (a writable copy: torch.from_numpy wants one)
+    else:
+        image = np.ascontiguousarray(path_or_array, np.uint8)
+    image_h, image_w = image.shape[0:2]
+    d = torch.from_numpy(image).to(device)
+    return ops.preprocess_u8(d, (shape[0], shape[1]), swap_rb=bgr, out=out), image_h, image_w
+
+
 def resize_bilinear_u8(img, out_w, out_h):
     """cv2.resize(img, (out_w, out_h)) INTER_LINEAR on uint8: half-pixel centres, edge clamp,
     11-bit fixed-point coefficients and round-half-up as OpenCV's 8-bit path does."""
