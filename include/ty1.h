@@ -75,8 +75,9 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
  * in fp32, output rounded to bf16 (nearest even).  Same reference lines as above
  * (/root/reference/models/model_tiny_yolov1.py:43-87); the reference itself computes in fp32, parity for this path
  * is a stated tolerance (tests/test_gpu_bf16.py).
- *   Cin == 3:  x (N,H,W,3) and w (Cout,3,3,3) are fp32 - the image enters in fp32 and the first layer stays an
- *              exact-fp32 convolution - y is bf16.  Needs W % 4 == 0, Cout <= 64.
+ *   Cin == 3:  x (N,H,W,3) and w (Cout,3,3,3) are passed in fp32 - the image enters the network in fp32 - and are
+ *              rounded to bf16 on the fly (one v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels); y is bf16.
+ *              Needs W % 4 == 0, Cout <= 64.
  *   Cin == 16: x, w, y bf16; Cout 32 or 64.
  *   Cin % 32 == 0: x, w bf16; Cout % 64 == 0; y bf16, or fp32 when out_f32 != 0 (pool == 0 only: the last conv
  *              layer feeds the fp32 Dense).

@@ -43,14 +43,16 @@ def _bf16(t):
 
 def backbone_ref(x_nhwc, params, return_all=False, bf16=False):
     """x (N,448,448,3) f32 NHWC -> (N,12544) flattened in HWC order.
-    bf16=True restates the build's bf16 network (BASELINE config 3; the reference itself is fp32 only): weights of
-    layers 1.. and the activations between layers are rounded to bf16, everything is accumulated in fp32, the last
-    layer's output stays fp32."""
+    bf16=True restates the build's bf16 network (BASELINE config 3; the reference itself is fp32 only): the image,
+    the conv weights and the activations between layers are rounded to bf16, everything is accumulated in fp32, the
+    last layer's output stays fp32."""
     x = torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
+    if bf16:
+        x = _bf16(x)
     acts = []
     for i in range(N_CONV):
         w = params[f'conv{i}_w']
-        if bf16 and i > 0:
+        if bf16:
             w = _bf16(torch.from_numpy(np.ascontiguousarray(w, np.float32))).numpy()
         x = conv_block_ref(x, w, params[f'bn{i}_gamma'], params[f'bn{i}_beta'],
                            params[f'bn{i}_mean'], params[f'bn{i}_var'], pool=i < N_POOL)

@@ -35,10 +35,13 @@ def _case(N, H, cin, cout, pool, out_f32, seed, use_ws):
     beta = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
     mean = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
     var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
-    if cin != 3:                      # what the kernel sees: bf16 activations and weights
-        x, w = bf16_round(x), bf16_round(w)
-    xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
-    ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
+    # the oracle sees what the MFMA sees: bf16 activations and weights (the first layer takes the fp32 image and
+    # fp32 weights and rounds them itself)
+    xr, wr = bf16_round(x), bf16_round(w)
+    if cin != 3:
+        x, w = xr, wr
+    xt = torch.from_numpy(xr).permute(0, 3, 1, 2).contiguous()
+    ref = model_ref.conv_block_ref(xt, wr, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
     scale, shift = ops.fold_bn(gamma, beta, mean, var)
     in_dt = torch.float32 if cin == 3 else torch.bfloat16
     ws = None

@@ -417,22 +417,32 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
 
-    // weights of this lane: B[k = 4*ks + kq][channel 16*j + i16]; k = 27 is the zero pad
-    float wreg[NT][7];
+    // f32 (exact):  7 x v_mfma_f32_16x16x4_f32 per 16-pixel tile, lane quarter kq supplies k = 4*ks + kq of step ks.
+    // OUT_BF16 (first layer of the bf16 network): image and weights are rounded to bf16 on the fly and a tile is
+    //               ONE v_mfma_f32_16x16x32_bf16, lane quarter kq supplies k = 8*kq .. 8*kq + 7.
+    // k = 27 .. 31 is the zero pad (weight 0, any valid LDS address).
+    constexpr int KS = OUT_BF16 ? 8 : 7;
+    auto k_of = [&](int ks) { return OUT_BF16 ? 8 * kq + ks : 4 * ks + kq; };
+    float wreg[NT][KS];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
-            const int k = 4 * ks + kq;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = k_of(ks);
             wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] : 0.f;
         }
-    // A-operand LDS offset of this lane for every k step, relative to the pixel's top-left tap
-    int koff[7];
+    bf16x8 wb[NT];
 #pragma unroll
-    for (int ks = 0; ks < 7; ++ks) {
-        const int k = 4 * ks + kq;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wb[j][e] = (__bf16)(OUT_BF16 ? wreg[j][e < KS ? e : 0] : 0.f);
+    // A-operand LDS offset of this lane for every k step, relative to the pixel's top-left tap
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = k_of(ks);
         const int kh = k / 9;
-        koff[ks] = k < 27 ? kh * C3_ROW + (k - 9 * kh) : 0;  // k = 27: any valid address (weight is 0)
+        koff[ks] = k < 27 ? kh * C3_ROW + (k - 9 * kh) : 0;
     }
     float sc[NT], sh[NT];
 #pragma unroll
@@ -493,9 +503,9 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     const int lane_px = 2 * (i16 >> 2) + (q & 1), lane_py = q >> 1;
     // LDS float index of this lane's A element for k step ks in M-tile (pr = 0, wcol = 0) of buffer 0; halo float 0
     // of a row is image float 3*x0 - 4, so pixel x0 - 1 starts at 1.  Every other tile is a compile-time offset.
-    int a_addr[7];
+    int a_addr[KS];
 #pragma unroll
-    for (int ks = 0; ks < 7; ++ks) a_addr[ks] = (4 * wave + lane_py) * C3_ROW + lane_px * 3 + 1 + koff[ks];
+    for (int ks = 0; ks < KS; ++ks) a_addr[ks] = (4 * wave + lane_py) * C3_ROW + lane_px * 3 + 1 + koff[ks];
     const float *lds = &tile[0][0];
 
     // Output: lane holds channel 16j + i16 of pool window kq (POOL) / of the 2x2 pixels of window kq, for every
@@ -546,34 +556,46 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         // output rows / columns of the image left from this lane's first element (a tile is valid below them)
         const int rows_left = Ho - oy0 - (POOL ? 2 : 4) * wave;
         const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * kq;
-        int ab[7];
+        int ab[KS];
 #pragma unroll
-        for (int ks = 0; ks < 7; ++ks) ab[ks] = a_addr[ks] + buf * ((C3_TH + 2) * C3_ROW);
+        for (int ks = 0; ks < KS; ++ks) ab[ks] = a_addr[ks] + buf * ((C3_TH + 2) * C3_ROW);
 
         // Two M-tiles (independent MFMA chains) per step; the BN / LeakyReLU / pool / store of a step is written
         // after the MFMAs of the NEXT step so that the scheduler can run it under them.
         // A operands of a step (7 k-steps x 2 tiles) are read from LDS one whole step ahead of their MFMAs
-        auto load_a = [&](int t2, float (&av)[7][2]) {
+        auto load_a = [&](int t2, float (&av)[KS][2]) {
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int t = t2 + u, pr = t >> 3, wc = t & 7;
                     av[ks][u] = lds[ab[ks] + 2 * pr * C3_ROW + 24 * wc];   // window 4*wc -> pixel 8*wc -> float 24*wc
                 }
         };
-        auto compute = [&](const float (&av)[7][2], f32x4 (&acc)[2][NT]) {
+        auto compute = [&](const float (&av)[KS][2], f32x4 (&acc)[2][NT]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (OUT_BF16) {
 #pragma unroll
-            for (int ks = 0; ks < 7; ++ks)
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 ab8;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][0], wreg[j][ks], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][1], wreg[j][ks], acc[1][j], 0, 0, 0);
+                    for (int e = 0; e < 8; ++e) ab8[e] = (__bf16)av[e < KS ? e : 0][u];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab8, wb[j], acc[u][j], 0, 0, 0);
                 }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][0], wreg[j][ks], acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][1], wreg[j][ks], acc[1][j], 0, 0, 0);
+                    }
+            }
         };
         auto finish = [&](int t2, const f32x4 (&acc)[2][NT]) {
 #pragma unroll
@@ -605,7 +627,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
             }
         };
         f32x4 accA[2][NT], accB[2][NT];
-        float avA[7][2], avB[7][2];
+        float avA[KS][2], avB[KS][2];
         load_a(0, avA);
         load_a(2, avB);
         compute(avA, accA);

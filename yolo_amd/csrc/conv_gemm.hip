@@ -1256,8 +1256,8 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
 }
 
 // bf16 network: activations and weights bf16, fp32 accumulate, folded BN in fp32.  out_f32 (pool == 0 only): the
-// layer stores fp32 (the last conv layer feeds the fp32 Dense).  Cin == 3: x and w are fp32 (the image enters in
-// fp32 and the first layer stays exact), y is bf16.
+// layer stores fp32 (the last conv layer feeds the fp32 Dense).  Cin == 3: x and w are passed in fp32 (the image
+// enters in fp32) and rounded to bf16 inside the kernel, y is bf16.
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
 int run_conv_bf16(const char *name, bool pool, bool out_f32, const ConvArgs &a, float *ws, size_t ws_bytes, size_t *ws_need,
                   hipStream_t s) {

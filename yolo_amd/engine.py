@@ -13,9 +13,9 @@ from .params import CONV_CHANNELS, N_POOL, BN_EPS, LEAKY_ALPHA, hwio_to_ohwi, de
 
 class DeviceModel:
     def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0', conv_specs=None, dtype='f32'):
-        """dtype 'f32': the reference's arithmetic.  dtype 'bf16' (BASELINE config 3): conv activations and
-        weights of layers 1.. in bf16 with fp32 accumulation; the image, the first layer's weights, BN, the last
-        conv layer's output, Dense, head and decode/NMS stay fp32."""
+        """dtype 'f32': the reference's arithmetic.  dtype 'bf16' (BASELINE config 3): conv operands (image, weights,
+        activations between layers) in bf16 with fp32 accumulation; BN, the last conv layer's output, Dense, head
+        and decode/NMS stay fp32."""
         if dtype not in ('f32', 'bf16'):
             raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
         self.dtype = dtype
