@@ -209,6 +209,8 @@ int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, f
  * launch count and summed milliseconds for kernels whose name starts with `prefix`.
  */
 int ty1_prof_enable(int on);
+/* Restrict the event brackets to launches whose name starts with `prefix` (NULL or "": all launches). */
+int ty1_prof_filter(const char *prefix);
 int ty1_prof_reset(void);
 int ty1_prof_query(const char *prefix, int *launches, double *total_ms);
 /* Writes up to cap bytes of "name launches total_ms\n" lines for every kernel seen. */

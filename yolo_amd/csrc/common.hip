@@ -32,12 +32,30 @@ struct ProfEntry {
     double ms = 0.0, flops = 0.0, bytes = 0.0;
 };
 static thread_local bool g_prof_on = false;
+static thread_local std::string g_prof_filter;              // non-empty: only launches whose name starts with it
 static thread_local std::map<std::string, ProfEntry> g_prof;
+static thread_local std::vector<hipEvent_t> g_event_pool;   // events are reused: creating two per launch is slow
+
+static hipEvent_t event_get() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 
 ProfScope::ProfScope(const char *n, hipStream_t s, double fl, double by)
     : name(n), stream(s), flops(fl), bytes(by), on(g_prof_on) {
     if (!on) return;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (!g_prof_filter.empty() && name.compare(0, g_prof_filter.size(), g_prof_filter) != 0) {
+        on = false;
+        return;
+    }
+    e0 = event_get();
+    e1 = event_get();
+    if (!e0 || !e1) {
         on = false;
         return;
     }
@@ -61,8 +79,8 @@ static void prof_collect() {
                 kv.second.ms += ms;
                 kv.second.launches += 1;
             }
-            (void)hipEventDestroy(p.first);
-            (void)hipEventDestroy(p.second);
+            g_event_pool.push_back(p.first);
+            g_event_pool.push_back(p.second);
         }
         kv.second.pending.clear();
     }
@@ -89,6 +107,11 @@ int ty1_fold_bn(const float *gamma, const float *beta, const float *mean, const 
 
 int ty1_prof_enable(int on) {
     ty1::g_prof_on = on != 0;
+    return 0;
+}
+
+int ty1_prof_filter(const char *prefix) {
+    ty1::g_prof_filter = prefix ? prefix : "";
     return 0;
 }
 

@@ -287,13 +287,20 @@ def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
 class KernelTimer:
     """HIP-event timing of every library launch on its own stream (bench.py roofline leg)."""
 
+    def __init__(self, only=None):
+        """only: time just the launches whose name starts with this prefix (two event records per launch cost a few
+        per cent of a step when every launch is bracketed)."""
+        self.only = only
+
     def __enter__(self):
         _lib.call('ty1_prof_reset')
+        _lib.call('ty1_prof_filter', self.only.encode() if self.only else b'')
         _lib.call('ty1_prof_enable', 1)
         return self
 
     def __exit__(self, *exc):
         _lib.call('ty1_prof_enable', 0)
+        _lib.call('ty1_prof_filter', b'')
 
     @staticmethod
     def table():
