@@ -24,19 +24,50 @@ __device__ __forceinline__ float np_maxf(float a, float b) {      // np.max: NaN
     return a >= b ? a : b;
 }
 
+// 64-lane all-reduce on the DPP crossbar (a ds_bpermute butterfly costs an LDS round trip per step): quad swaps,
+// half-row and row mirrors leave every lane of a 16-lane row with the row's result, the four rows are then combined
+// from lanes 15 / 31 / 47 / 63.  Both operators are commutative and associative (NaN propagates through np_maxf
+// whatever the order), so the result does not depend on the reduction tree.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(dpp_i<CTRL>(__float_as_int(v)));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
+
 __device__ __forceinline__ float wave_np_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = np_maxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = np_maxf(v, dpp_f<kQuadXor1>(v));
+    v = np_maxf(v, dpp_f<kQuadXor2>(v));
+    v = np_maxf(v, dpp_f<kRowHalfMirror>(v));
+    v = np_maxf(v, dpp_f<kRowMirror>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return np_maxf(np_maxf(r0, r1), np_maxf(r2, r3));
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    int o;
+    o = dpp_i<kQuadXor1>(v); v = o > v ? o : v;
+    o = dpp_i<kQuadXor2>(v); v = o > v ? o : v;
+    o = dpp_i<kRowHalfMirror>(v); v = o > v ? o : v;
+    o = dpp_i<kRowMirror>(v); v = o > v ? o : v;
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31);
+    const int r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+    const int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+}
+
+// value of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ double wave_bcast_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
 // tiny_yolov1.py:58-72 in float64; np.maximum/np.minimum propagate NaN.
@@ -168,10 +199,10 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict
 #pragma unroll
         for (int k = 1; k < B; ++k)
             if (kl == k) { sel[0] = mn[k][0]; sel[1] = mn[k][1]; sel[2] = mx[k][0]; sel[3] = mx[k][1]; }
-        smin[0] = __shfl(sel[0], owner, 64);
-        smin[1] = __shfl(sel[1], owner, 64);
-        smax[0] = __shfl(sel[2], owner, 64);
-        smax[1] = __shfl(sel[3], owner, 64);
+        smin[0] = wave_bcast_f64(sel[0], owner);
+        smin[1] = wave_bcast_f64(sel[1], owner);
+        smax[0] = wave_bcast_f64(sel[2], owner);
+        smax[1] = wave_bcast_f64(sel[3], owner);
         lmax = NEG_INF;
 #pragma unroll
         for (int k = 0; k < B; ++k) {
