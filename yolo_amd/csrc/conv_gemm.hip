@@ -1,30 +1,29 @@
-// Implicit-GEMM 3x3 convolution (+ folded BatchNorm + LeakyReLU + 2x2/2 max-pool epilogue) and the
-// split-K Dense GEMM, on the exact-f32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM 3x3 convolution (+ folded BatchNorm + LeakyReLU + 2x2/2 max-pool epilogue) on the matrix cores of
+// gfx950: exact-f32 v_mfma_f32_32x32x2_f32, or v_mfma_f32_32x32x16_bf16 for the bf16 network.
 //
-// Replaces /root/reference/models/model_tiny_yolov1.py:43-87 (conv blocks) and :96 (Dense matmul).
+// Replaces /root/reference/models/model_tiny_yolov1.py:43-87 (conv blocks).  The Dense matmul is dense_gemm.hip, the
+// shallow layers (Cin = 3, 16) are conv_direct.hip.
 //
-// GEMM view:  M = output pixels (N*H*W), N = Cout, K = TAPS*Cin (k = tap*Cin + ci).
+// GEMM view:  M = output pixels (N*H*W), N = Cout, K = 9*Cin (k = tap*Cin + ci).
 //   A[m][k]  is gathered on the fly from the NHWC input (zero outside the image),
 //   B[n][k]  is the OHWI weight matrix ([Cout][9*Cin]), so both LDS tiles are [row][k] with k
-//            contiguous and every lane fetches four k values with one ds_read_b128.
+//            contiguous and every lane fetches 16 bytes of k with one ds_read_b128.
 // For pooled layers the M index is ordered m = 4*window + (dy*2+dx): the four pixels of one
 // 2x2 pool window are the four accumulator registers (reg&3) one lane already holds for one
 // channel (MFMA 32x32 C/D layout row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so the max-pool is
 // three v_max in registers and the pre-pool tensor never touches HBM.
 //
 // Block: 256 threads = 4 waves (WAVES_M x WAVES_N), each wave WM x WN tiles of 32x32.
-// K loop: chunks of BK floats, double-buffered in LDS (row stride BK+4 floats: conflict-free for
-// the ds_read_b128 16-lane groups), next chunk prefetched into registers during the MFMAs.
 //
-// Grid quantisation.  Every tile of a layer costs the same, two tiles share a CU, and the tile
+// Grid quantisation.  Every tile of a layer costs the same, two to four tiles share a CU, and the tile
 // count of this network is always 49 * 2^k: a plain grid leaves up to a quarter of the chip idle in
 // its last round (784 tiles on 256 CUs = 3.06 rounds).  A layer is therefore run as
-//   (1) the largest multiple of the CU count of whole tiles, fused epilogue, then
-//   (2) the remaining R < #CU tiles split s ways along K (R*s ~ a multiple of #CU short blocks that
+//   (1) the largest multiple of the CU count of whole tiles, fused epilogue, and in the same launch
+//   (2) the remaining R < #CU tiles split s ways along K (R*s ~ a multiple of #CU short pieces that
 //       write raw accumulator tiles to a caller-provided workspace), then
 //   (3) a small fix-up kernel that sums the s partials and applies BN/LeakyReLU/max-pool.
 // plan_tail() picks s with a cost model in units of one K chunk; without a workspace the layer runs
-// as one plain grid (same results, slower tail).
+// as whole tiles only (same results up to summation order, slower tail).
 #include "common.h"
 
 #include <cmath>
@@ -37,38 +36,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 
-enum : int { kFused = 0, kDenseRaw = 1, kTileRaw = 2 };
-
+// one conv problem as the dispatcher hands it to a tile configuration (x / w / y hold bf16 data behind their float
+// pointers in the bf16 network)
 struct ConvArgs {
-    const float *x;      // A source: NHWC input (conv) or [M][K] row-major (dense)
-    const float *w;      // [Nvalid rows][ldw] weights, k contiguous
-    const float *scale;  // per output channel (conv epilogue)
+    const float *x;      // NHWC input
+    const float *w;      // [Cout][9*Cin] weights, k contiguous
+    const float *scale;  // folded BN, per output channel
     const float *shift;
-    float *y;            // output (kFused), dense partials (kDenseRaw) or tile partials (kTileRaw)
-    int NB, H, W, Cin;   // input geometry (dense: H=W=1, Cin=K)
-    int Cout;            // GEMM N (valid rows of w)
-    int ldw;             // row stride of w in floats
-    int ldy;             // dense: row stride of the output partials
-    int M;               // GEMM rows (pre-pool pixels or dense batch rows)
-    int chunks_total;    // K / BK
-    int splits;          // gridDim.y: block (.., s) reduces chunks [chunks_total*s/splits, chunks_total*(s+1)/splits)
+    float *y;
+    int NB, H, W, Cin, Cout;
+    int M;               // GEMM rows = pre-pool pixels
     float alpha;
-    int mtiles, ntiles;
-    int tile_begin;      // this launch covers logical tiles [tile_begin, tile_begin + gridDim.x)
-    long long *stamp;    // developer timeline buffer (8 x i64 per block) or nullptr
-    long long stamp_cap; // rows of 8 i64 in stamp
 };
 
 using ty1::g_stamp;
 using ty1::g_stamp_cap;
-
-__device__ __forceinline__ void stamp(const ConvArgs &a, int slot) {
-    if (a.stamp && threadIdx.x == 0) {
-        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-        if (slot == 1 || slot == 2)
-            a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5 + slot] = __builtin_amdgcn_s_memtime();
-    }
-}
 
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (private L2), so give every XCD a
 // contiguous range of logical tile ids (neighbouring tiles share halo rows and weight panels).
@@ -78,324 +60,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, int MODE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_gemm_f32_kernel(const ConvArgs a) {
-    static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves per block");
-    constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
-    constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    constexpr int LDS_STRIDE = BK + 4;
-    constexpr int CPR = BK / 4;               // 16-byte pieces per tile row
-    constexpr int RPP = NTHREADS / CPR;       // tile rows covered per pass
-    constexpr int AP = (BM + RPP - 1) / RPP;  // passes for the A tile
-    constexpr int BP = (BN + RPP - 1) / RPP;  // passes for the B tile
-
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-
-    stamp(a, 0);
-    if (a.stamp && threadIdx.x == 0) {
-        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        a.stamp[(long long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-    const int tile_local = xcd_remap(blockIdx.x, gridDim.x);
-    const int logical = a.tile_begin + tile_local;
-    const int mt = logical / a.ntiles, nt = logical - mt * a.ntiles;
-    const int split = blockIdx.y;
-
-    const int piece = tid % CPR, prow = tid / CPR;
-
-    // ---- operands are fetched with raw buffer loads: an out-of-range offset returns 0, which gives the
-    //      zero padding of the 3x3 halo, the M / N tails and a branch-free K loop (one basic block that
-    //      the scheduler can interleave with the MFMAs).  Offsets are 32-bit bytes relative to the first
-    //      image this block touches, so tensors larger than 4 GiB still work.
-    constexpr unsigned kOOB = 0xFFFFFFFFu;
-    const int m_first = mt * BM;
-    long long a_origin;                       // element offset of the block's buffer base inside x
-    if (TAPS == 1) {
-        a_origin = (long long)m_first * a.Cin;
-    } else {
-        const int img = POOL ? (m_first >> 2) / ((a.H >> 1) * (a.W >> 1)) : m_first / (a.H * a.W);
-        a_origin = (long long)img * a.H * a.W * a.Cin;
-    }
-    // block-uniform by construction; say so, or the buffer resource below is treated as divergent (waterfall loops)
-    a_origin = ((long long)__builtin_amdgcn_readfirstlane((int)(a_origin >> 32)) << 32) |
-               (unsigned)__builtin_amdgcn_readfirstlane((int)a_origin);
-    const long long a_total = (TAPS == 1 ? (long long)a.M : (long long)a.NB * a.H * a.W) * a.Cin;
-    const long long a_left = (a_total - a_origin) * 4;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x + a_origin), 0, (int)(a_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : a_left), 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.w), 0, (int)((long long)a.Cout * a.ldw * 4), 0x00020000);
-
-    unsigned a_base[AP];                      // byte offset of the row's centre pixel (or row start)
-    unsigned a_mask[AP];                      // bit t: tap t lies inside the image
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-        const int row = p * RPP + prow;
-        const int m = m_first + row;
-        a_base[p] = 0;
-        a_mask[p] = 0;
-        if (row < BM && m < a.M) {
-            if (TAPS == 1) {
-                a_base[p] = (unsigned)((long long)row * a.Cin * 4);
-                a_mask[p] = 1;
-            } else {
-                int n, yy, xx;
-                if (POOL) {
-                    const int Hp = a.H >> 1, Wp = a.W >> 1;
-                    const int win = m >> 2, q = m & 3;
-                    n = win / (Hp * Wp);
-                    const int rem = win - n * (Hp * Wp);
-                    const int py = rem / Wp, px = rem - py * Wp;
-                    yy = 2 * py + (q >> 1);
-                    xx = 2 * px + (q & 1);
-                } else {
-                    n = m / (a.H * a.W);
-                    const int rem = m - n * (a.H * a.W);
-                    yy = rem / a.W;
-                    xx = rem - yy * a.W;
-                }
-                const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - a_origin;
-                a_base[p] = (unsigned)(el * 4);
-                unsigned mask = 0;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-                    if (y2 >= 0 && y2 < a.H && x2 >= 0 && x2 < a.W) mask |= 1u << t;
-                }
-                a_mask[p] = mask;
-            }
-        }
-    }
-    unsigned b_base[BP];
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-        const int row = p * RPP + prow;
-        const int n = nt * BN + row;
-        b_base[p] = (row < BN && n < a.Cout) ? (unsigned)((long long)n * a.ldw * 4) : kOOB;
-    }
-
-    const int chunks_per_tap = a.Cin / BK;
-    const int kc_begin = (int)((long long)a.chunks_total * split / a.splits);
-    const int kc_end = (int)((long long)a.chunks_total * (split + 1) / a.splits);
-
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[AP], rb[BP];
-    // fetch cursor: chunk ld_kc = (tap ld_tap, channel offset ld_ci0); advanced incrementally (no division in the loop)
-    int ld_kc = kc_begin, ld_tap = 0, ld_ci0 = kc_begin * BK;
-    if (TAPS != 1) {
-        ld_tap = kc_begin / chunks_per_tap;
-        ld_ci0 = (kc_begin - ld_tap * chunks_per_tap) * BK;
-    }
-    auto load_chunk = [&]() {                 // past kc_end every lane goes out of range and nothing is fetched
-        const bool live = ld_kc < kc_end;
-        const int dy = TAPS == 1 ? 0 : ld_tap / 3 - 1, dx = TAPS == 1 ? 0 : ld_tap - 3 * (ld_tap / 3) - 1;
-        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0 + piece * 4) * 4;   // bytes, may be negative
-        const unsigned tapbit = live ? 1u << ld_tap : 0u;
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const unsigned off = (a_mask[p] & tapbit) ? a_base[p] + (unsigned)delta : kOOB;
-            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
-        }
-        const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
-#pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const unsigned off = (b_base[p] == kOOB || !live) ? kOOB : b_base[p] + koff;
-            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
-        }
-        ++ld_kc;
-        ld_ci0 += BK;
-        if (TAPS != 1) {                          // branch-free wrap to the next tap
-            const bool wrap = ld_ci0 == a.Cin;
-            ld_ci0 = wrap ? 0 : ld_ci0;
-            ld_tap += wrap ? 1 : 0;
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const int row = p * RPP + prow;
-            if (AP * RPP == BM || row < BM) *reinterpret_cast<u32x4 *>(&As[buf][row * LDS_STRIDE + piece * 4]) = ra[p];
-        }
-#pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const int row = p * RPP + prow;
-            if (BP * RPP == BN || row < BN) *reinterpret_cast<u32x4 *>(&Bs[buf][row * LDS_STRIDE + piece * 4]) = rb[p];
-        }
-    };
-
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
-    const int a_row0 = wave_m * (32 * WM) + frag_row;
-    const int b_row0 = wave_n * (32 * WN) + frag_row;
-
-    // One k-block (8 k values: each lane holds 4 of them, the MFMA pairs lane halves) of A and B fragments.
-    struct Frag {
-        float a[WM][4], b[WN][4];
-    };
-    auto read_frag = [&](Frag &f, int buf, int kb) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(
-                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k], 16));
-            f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
-        }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(
-                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k], 16));
-            f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
-        }
-    };
-    auto mfma = [&](const Frag &f, int k0, int k1) {        // WM*WN*(k1-k0) MFMAs
-#pragma unroll
-        for (int k = k0; k < k1; ++k)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
-    };
-    constexpr int NKB = BK / 8;
-    static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
-
-    load_chunk();
-    store_chunk(0);
-    load_chunk();                                 // chunk kc_begin + 1 (nothing if the range has one chunk)
-    __syncthreads();
-    stamp(a, 1);
-
-    // Software pipeline of one wave (the matrix pipe should never wait for this wave's own memory work).
-    // Per chunk, right after the barrier that published it:
-    //   1. read the fragments of its first k-block                (latency hidden by 2.)
-    //   2. store the NEXT chunk (fetched a whole chunk ago) to the other LDS buffer and immediately re-issue
-    //      the fetch of the chunk after that into the same registers; the 32 KB of LDS stores per block
-    //      (the VGPR->LDS path moves ~79 B/clk per CU) drain behind the MFMAs that follow
-    //   3. the second half of the previous chunk's last k-block (8 MFMAs kept back across the barrier)
-    //   4. k-blocks 0..NKB-1 with the fragments of k-block kb+1 read while k-block kb multiplies
-    //   5. barrier with half of the last k-block still to issue.
-    Frag f0, f1;
-    auto kblocks = [&](int buf, int tail) {       // k-blocks 0..NKB-1 of one chunk; the last one multiplies k < tail only
-        read_frag(f1, buf, 1);
-        mfma(f0, 0, 4);
-        if (NKB == 4) {
-            read_frag(f0, buf, 2);
-            mfma(f1, 0, 4);
-            read_frag(f1, buf, 3);
-            mfma(f0, 0, 4);
-        }
-        mfma(f1, 0, tail);
-    };
-    // The loop body is the same for every chunk (one basic block, no peeling: peeled copies make the register
-    // allocator shuffle the 64 accumulator registers around the loop).  The first pass multiplies a zero
-    // fragment in step 3, the last pass stores / fetches nothing real (the fetch cursor is past kc_end).
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f1.b[j][k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f1.a[i][k] = 0.f;
-    int buf = 0;
-    read_frag(f0, 0, 0);
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-        store_chunk(buf ^ 1);                     // that buffer was last read before the previous barrier
-        load_chunk();
-        mfma(f1, 2, 4);
-        kblocks(buf, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        buf ^= 1;
-        read_frag(f0, buf, 0);
-    }
-    mfma(f1, 2, 4);
-
-    stamp(a, 2);
-    // ---- epilogue.  Lane holds channel (lane&31) of tile column j; register r is tile row
-    //      (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const int h = lane >> 5;
-    if (MODE == kTileRaw) {
-        // raw accumulator tile -> workspace [split][tile_local][BM][BN]; fixed up by conv_fixup_kernel
-        float *out = a.y + ((long long)split * gridDim.x + tile_local) * (BM * BN);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = wave_n * (32 * WN) + 32 * j + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const int row0 = wave_m * (32 * WM) + 32 * i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) out[(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) * BN + col] = acc[i][j][r];
-            }
-        }
-        stamp(a, 3);
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
-        if (n >= a.Cout) continue;
-        float sc = 1.f, sh = 0.f;
-        if (MODE == kFused) {
-            sc = a.scale[n];
-            sh = a.shift[n];
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const int m0 = mt * BM + wave_m * (32 * WM) + 32 * i;
-            if (MODE == kDenseRaw) {
-                float *out = a.y + (long long)split * a.M * a.ldy;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < a.M) out[(long long)m * a.ldy + n] = acc[i][j][r];
-                }
-            } else if (POOL) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float t = acc[i][j][4 * g + q] * sc + sh;
-                        v[q] = t > 0.f ? t : t * a.alpha;
-                    }
-                    const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    const int win = (m0 >> 2) + 2 * g + h;
-                    if (win * 4 < a.M) a.y[(long long)win * a.Cout + n] = pooled;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float t = acc[i][j][r] * sc + sh;
-                    t = t > 0.f ? t : t * a.alpha;
-                    if (m < a.M) a.y[(long long)m * a.Cout + n] = t;
-                }
-            }
-        }
-    }
-    stamp(a, 3);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Persistent conv kernel.  The grid is two workgroups per CU; workgroup b walks the work items
 // slot(b), slot(b) + G, slot(b) + 2G ... (item = output tile x K-split piece) as ONE continuous stream of
 // K chunks: the fetch cursor runs two chunks ahead of the MFMAs and simply crosses into the next item,
 // so a new tile starts with its operands already in LDS - no per-tile prologue (address arithmetic +
 // an exposed HBM round trip, 4-10 us per tile when every tile was its own workgroup) and no drain.
-// Loop body = the software pipeline described in conv_gemm_f32_kernel.  Row geometry (image, y, x of
-// every GEMM row of a tile, 3x3 validity mask) is recomputed per item with multiply-shift division.
+// Row geometry (image, y, x of every GEMM row of a tile, 3x3 validity mask) is recomputed per item with
+// multiply-shift division.
+// Software pipeline of one wave (the matrix pipe should never wait for this wave's own memory work).  Per chunk, right
+// after the barrier that published it:
+//   1. read the fragments of its first k-block                (latency hidden by 2.)
+//   2. store the NEXT chunk (fetched a whole chunk ago) to the other LDS buffer and immediately re-issue the fetch of
+//      the chunk after that into the same registers; the 32 KB of LDS stores per block (the VGPR->LDS path moves
+//      ~79 B/clk per CU) drain behind the MFMAs that follow
+//   3. the second half of the previous chunk's last k-block (8 MFMAs kept back across the barrier)
+//   4. k-blocks 0..NKB-1 with the fragments of k-block kb+1 read while k-block kb multiplies
+//   5. barrier with half of the last k-block still to issue; 6. cursor step (the only branch of the body).
+// The body is the same for every chunk (no peeling: peeled copies make the register allocator shuffle the 64
+// accumulator registers around the loop); an item's first pass multiplies a zero fragment in step 3.
 // ------------------------------------------------------------------------------------------------
 struct FastDiv {         // q = n / d for 0 <= n < 2^31:  (mulhi(n, M) + n) >> l
     unsigned M, l;
@@ -1101,20 +784,6 @@ TailPlan plan_tail(int T, int C, int slots) {
     return p;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAPS, bool POOL, int MODE>
-int launch_gemm(const char *name, ConvArgs a, int tiles, int splits, double flops, double bytes, hipStream_t s) {
-    dim3 grid(tiles, splits), block(64 * WAVES_M * WAVES_N);
-    a.splits = splits;
-    a.stamp = (g_stamp && 2ll * grid.x * grid.y <= g_stamp_cap) ? g_stamp : nullptr;
-    a.stamp_cap = g_stamp_cap;
-    char tag[96];
-    snprintf(tag, sizeof tag, "%s@%dx%d>%d", name, a.H, a.Cin, a.Cout);
-    ty1::ProfScope prof(tag, s, flops, bytes);
-    static const char *pad = getenv("TY1_LDS_PAD");          // developer: extra dynamic LDS bytes (lowers occupancy)
-    conv_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, BK, TAPS, POOL, MODE><<<grid, block, pad ? atoi(pad) : 0, s>>>(a);
-    return ty1::check_launch(name);
-}
-
 // One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: one persistent launch over the whole
 // tiles and the K pieces of the tail, then the fix-up of the tail tiles.
 // ws_need != nullptr: size query only (returns the workspace bytes the plan wants).
@@ -1222,7 +891,7 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
                     "ty1_conv3x3: x, w and workspace must be 16-byte aligned");
     ConvArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
-    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = 9 * Cin; a.ldy = Cout;
+    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.M = N * H * W;
     a.alpha = alpha;
     const bool p = pool != 0;
@@ -1302,7 +971,7 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
     ConvArgs a{};
     a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w); a.scale = scale; a.shift = shift;
     a.y = static_cast<float *>(y);
-    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldw = 9 * Cin; a.ldy = Cout;
+    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.M = N * H * W;
     a.alpha = alpha;
     const bool p = pool != 0, of = out_f32 != 0;
@@ -1368,32 +1037,4 @@ extern "C" int ty1_conv3x3_bn_leaky_f32(const float *x, const float *w, const fl
                                         float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
                                         ty1_stream_t stream) {
     return conv3x3_dispatch(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, nullptr, 0, nullptr, (hipStream_t)stream);
-}
-
-extern "C" int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units, int ldk,
-                                    int ldz, int splits, ty1_stream_t stream) {
-    TY1_REQUIRE(N >= 0 && K > 0 && units > 0 && splits > 0, "ty1_dense_splitk: bad dimensions");
-    if (N == 0) return 0;
-    TY1_REQUIRE(x && wt && part, "ty1_dense_splitk: null pointer");
-    TY1_REQUIRE(ldk >= K && ldk % 4 == 0 && K % 4 == 0, "ty1_dense_splitk: ldk=%d must be >= K=%d, both multiples of 4", ldk, K);
-    TY1_REQUIRE(ldz >= units, "ty1_dense_splitk: ldz=%d < units=%d", ldz, units);
-    TY1_REQUIRE(K % 32 == 0 && splits <= K / 32, "ty1_dense_splitk: K=%d must be a multiple of 32 and splits=%d at most K/32", K, splits);
-    TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wt & 15) == 0, "ty1_dense_splitk: x and wt must be 16-byte aligned");
-    ConvArgs a{};
-    a.x = x; a.w = wt; a.y = part;
-    a.NB = N; a.H = 1; a.W = 1; a.Cin = K; a.Cout = units; a.ldw = ldk; a.ldy = ldz;
-    a.M = N;
-    a.alpha = 0.f;
-    a.chunks_total = K / 32;
-    a.tile_begin = 0;
-    hipStream_t s = (hipStream_t)stream;
-    const double flops = 2.0 * N * (double)units * K, bytes = 4.0 * ((double)N * K + (double)units * K + (double)splits * N * units);
-    if (N <= 32) {
-        a.mtiles = (N + 31) / 32;
-        a.ntiles = (units + 127) / 128;
-        return launch_gemm<1, 1, 1, 4, 32, 1, false, kDenseRaw>("dense_f32_32x128", a, a.mtiles * a.ntiles, splits, flops, bytes, s);
-    }
-    a.mtiles = (N + 63) / 64;
-    a.ntiles = (units + 63) / 64;
-    return launch_gemm<1, 1, 2, 2, 32, 1, false, kDenseRaw>("dense_f32_64x64", a, a.mtiles * a.ntiles, splits, flops, bytes, s);
 }
