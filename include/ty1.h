@@ -217,9 +217,9 @@ int ty1_prof_query(const char *prefix, int *launches, double *total_ms);
 int ty1_prof_dump(char *buf, size_t cap);
 
 /*
- * Developer hook (no reference counterpart): when buf != NULL, every later conv/dense GEMM launch with
- * at most cap_blocks workgroups writes 8 int64 per workgroup: s_memrealtime (100 MHz) at start, after the
- * prologue, after the K loop, at the end; HW_ID; XCC_ID.  Pass NULL to switch it off.
+ * Developer hook (no reference counterpart): when buf != NULL, every later persistent conv launch with at most
+ * cap_blocks workgroups writes 8 int64 per workgroup: s_memrealtime (100 MHz) at start and end, cycles spent in the
+ * K loops / epilogues / geometry, HW_ID, XCC_ID, item count (tools/stamp_trace.py).  Pass NULL to switch it off.
  */
 int ty1_debug_stamp_buffer(long long *buf, long long cap_blocks);
 

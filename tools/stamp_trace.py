@@ -63,33 +63,4 @@ if args.persist:
           'index distance of CU partners:', dict(zip(*[x.tolist() for x in np.unique(diffs, return_counts=True)])))
     print('xcc of blocks 0..15:', xcc[:16].tolist())
     sys.exit(0)
-st, pro, loop, end = ((b[:, i] - t0) / 100.0 for i in range(4))     # microseconds
-hw = b[:, 4]
-cu = (hw >> 8) & 0xF
-sh_ = (hw >> 12) & 1
-se = (hw >> 13) & 0x7
-xcc = b[:, 5] & 0xF
-cuid = ((xcc * 8 + se) * 2 + sh_) * 16 + cu
-print(f'blocks {len(b)}  kernel span {end.max():.1f} us  distinct CU ids {len(np.unique(cuid))}')
-print(f'prologue  mean {np.mean(pro - st):7.1f} us  max {np.max(pro - st):7.1f}')
-print(f'loop      mean {np.mean(loop - pro):7.1f} us  min {np.min(loop - pro):7.1f} max {np.max(loop - pro):7.1f}')
-cyc = (b[:, 7] - b[:, 6]).astype(np.float64)
-print(f'loop shader cycles mean {cyc.mean():.0f} -> clock {np.mean(cyc / (loop - pro)) / 1e3:.3f} GHz')
-print(f'epilogue  mean {np.mean(end - loop):7.1f} us  max {np.max(end - loop):7.1f}')
-print('start-time histogram (us):', np.histogram(st, bins=10)[0].tolist(), f'first {st.min():.1f} last {st.max():.1f}')
-print('end-time   histogram (us):', np.histogram(end, bins=10)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
-per_cu = {}
-for c, s_, e_ in zip(cuid, st, end):
-    per_cu.setdefault(int(c), []).append((s_, e_))
-cnt = np.array([len(v) for v in per_cu.values()])
-print('blocks per CU: min', cnt.min(), 'max', cnt.max(), 'hist', np.bincount(cnt).tolist())
-busy_end = np.array([max(e for _, e in v) for v in per_cu.values()])
-print(f'per-CU last end: min {busy_end.min():.1f} mean {busy_end.mean():.1f} max {busy_end.max():.1f}')
-c0 = sorted(per_cu[list(per_cu)[0]])
-import os as _os
-if _os.environ.get('TY1_DIAG'):
-    d = ball[cap // 2:cap // 2 + nb].astype(np.float64)
-    it = np.maximum(d[:, 3], 1)
-    print(f'DIAG per iteration (shader cycles), wave0: vmcnt wait {np.mean(d[:, 0] / it):.0f}  lds store {np.mean(d[:, 1] / it):.0f}  barrier {np.mean(d[:, 2] / it):.0f};'
-          f'  wave3: vmcnt {np.mean(d[:, 4] / it):.0f} store {np.mean(d[:, 5] / it):.0f} barrier {np.mean(d[:, 6] / it):.0f};  loop cycles/iter {np.mean(cyc / (it + 1)):.0f}')
-print('one CU timeline:', [(round(a, 1), round(b_, 1)) for a, b_ in c0])
+sys.exit('pass --persist (conv_persist_kernel layers) or --direct (first layer, TY1_DEV_STAMPS build)')
