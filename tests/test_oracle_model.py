@@ -58,3 +58,22 @@ def test_flatten_is_hwc_and_dense_is_x_at_w():
     w = rng.standard_normal((5, 4)).astype(np.float32)
     b = rng.standard_normal(4).astype(np.float32)
     np.testing.assert_allclose(model_ref.dense_ref(x, w, b), x.astype(np.float64) @ w + b, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_restatement_rounds_where_the_build_rounds():
+    """backbone_ref(bf16=True) states the build's bf16 network: image, conv weights and the activations between
+    layers are bf16 values (8 significant bits), the last layer's output is not rounded, and the result stays close
+    to the fp32 restatement."""
+    import torch
+    from yolo_amd import params as P
+    prm = P.make_random_params(seed=3, dense_init='glorot', bn='random')
+    x = np.random.default_rng(0).random((1, 64, 64, 3)).astype(np.float32)       # a small image: 64 -> 1x1 after 6 pools
+    f32, acts32 = model_ref.backbone_ref(x, prm, return_all=True)
+    b16, acts16 = model_ref.backbone_ref(x, prm, return_all=True, bf16=True)
+
+    def is_bf16(a):
+        return np.array_equal(torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy(), a)
+    assert all(is_bf16(a) for a in acts16[:-1]) and not is_bf16(acts16[-1])
+    for a32, a16 in zip(acts32, acts16):
+        assert np.abs(a16 - a32).max() <= 3e-2 * max(1.0, np.abs(a32).max())
+    assert b16.shape == f32.shape
