@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_amd import params as P
 from yolo_amd.engine import DeviceModel
 dev = torch.device('cuda', 0)
-N = 64
+N = int(os.environ.get("N", "64"))
 prm = P.make_random_params(seed=1, C=20, dense_init='glorot', bn='identity')
 model = DeviceModel(prm, C=20, device=dev)
 x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(0)).to(dev)
