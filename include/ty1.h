@@ -79,8 +79,7 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
  *              rounded to bf16 on the fly (one v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels); y is bf16.
  *              Needs W % 4 == 0, Cout <= 64.
  *   Cin == 16: x, w, y bf16; Cout 32 or 64.
- *   Cin % 32 == 0: x, w bf16; Cout % 64 == 0; y bf16, or fp32 when out_f32 != 0 (pool == 0 only: the last conv
- *              layer feeds the fp32 Dense).
+ *   Cin % 32 == 0: x, w bf16; Cout % 64 == 0; y bf16, or fp32 when out_f32 != 0 (pool == 0 only).
  *   alpha >= 0.  workspace as for ty1_conv3x3_bn_leaky_ws_f32 (size from ty1_conv3x3_workspace_bytes_bf16; may be NULL).
  * ty1_cast_f32_to_bf16 converts n floats to bf16 (round to nearest even), e.g. the weights at model load.
  */
@@ -112,6 +111,9 @@ int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int swap_rb, flo
  */
 int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units,
                          int ldk, int ldz, int splits, ty1_stream_t stream);
+/* The same for the bf16 network: x and wt hold bf16, part stays fp32; K a multiple of 64, splits <= K/64. */
+int ty1_dense_splitk_bf16(const void *x, const void *wt, float *part, int N, int K, int units,
+                          int ldk, int ldz, int splits, ty1_stream_t stream);
 
 /*
  * z = sum_s part[s] + bias ; y = concat(softmax_C(z_cls), sigmoid(z_conf), sigmoid(z_box))

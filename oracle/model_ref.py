@@ -44,8 +44,7 @@ def _bf16(t):
 def backbone_ref(x_nhwc, params, return_all=False, bf16=False):
     """x (N,448,448,3) f32 NHWC -> (N,12544) flattened in HWC order.
     bf16=True restates the build's bf16 network (BASELINE config 3; the reference itself is fp32 only): the image,
-    the conv weights and the activations between layers are rounded to bf16, everything is accumulated in fp32, the
-    last layer's output stays fp32."""
+    the conv weights and every layer's output are rounded to bf16, everything is accumulated in fp32."""
     x = torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2).contiguous()
     if bf16:
         x = _bf16(x)
@@ -56,7 +55,7 @@ def backbone_ref(x_nhwc, params, return_all=False, bf16=False):
             w = _bf16(torch.from_numpy(np.ascontiguousarray(w, np.float32))).numpy()
         x = conv_block_ref(x, w, params[f'bn{i}_gamma'], params[f'bn{i}_beta'],
                            params[f'bn{i}_mean'], params[f'bn{i}_var'], pool=i < N_POOL)
-        if bf16 and i < N_CONV - 1:
+        if bf16:
             x = _bf16(x)
         if return_all:
             acts.append(x.permute(0, 2, 3, 1).contiguous().numpy())
@@ -64,8 +63,12 @@ def backbone_ref(x_nhwc, params, return_all=False, bf16=False):
     return (flat.numpy(), acts) if return_all else flat.numpy()
 
 
-def dense_ref(x, w, b):
-    return (torch.from_numpy(x) @ torch.from_numpy(np.ascontiguousarray(w)) + torch.from_numpy(b)).numpy()
+def dense_ref(x, w, b, bf16=False):
+    """bf16=True: features and weights rounded to bf16 (the build's bf16 Dense), fp32 accumulation and bias."""
+    xt, wt = torch.from_numpy(np.ascontiguousarray(x)), torch.from_numpy(np.ascontiguousarray(w))
+    if bf16:
+        xt, wt = _bf16(xt), _bf16(wt)
+    return (xt @ wt + torch.from_numpy(b)).numpy()
 
 
 def head_activate_ref(z, S=7, B=2, C=20):
@@ -82,7 +85,7 @@ def head_activate_ref(z, S=7, B=2, C=20):
 
 def model_ref(x_nhwc, params, S=7, B=2, C=20, bf16=False):
     feats = backbone_ref(x_nhwc, params, bf16=bf16)
-    z = dense_ref(feats, params['dense_w'], params['dense_b'])
+    z = dense_ref(feats, params['dense_w'], params['dense_b'], bf16=bf16)
     return head_activate_ref(z, S, B, C)
 
 

@@ -124,7 +124,7 @@ def test_model_bf16_end_to_end(dense_init):
         err = np.abs(g - a_ref).max() / max(1.0, np.abs(a_ref).max())
         print(f'layer {i}: max err / max |ref| = {err:.2e}')
         assert err < 2e-2
-    z_a = model_ref.dense_ref(feats_a, prm['dense_w'], prm['dense_b'])
+    z_a = model_ref.dense_ref(feats_a, prm['dense_w'], prm['dense_b'], bf16=True)
     z_b = model_ref.dense_ref(model_ref.backbone_ref(x, prm), prm['dense_w'], prm['dense_b'])
     rms = float(np.sqrt((z_b ** 2).mean()))
     ea, eb = np.abs(z - z_a).max() / rms, np.abs(z - z_b).max() / rms
@@ -137,3 +137,18 @@ def test_model_bf16_end_to_end(dense_init):
     want = oracle.decode_nms(y, 2, 20, 448)
     assert np.array_equal(keep, want['keep']) and np.array_equal(cls, want['cls'])
     assert np.array_equal(boxes.view(np.uint64), np.ascontiguousarray(want['boxes']).view(np.uint64))
+
+
+@pytest.mark.parametrize('N,units', [(1, 1470), (64, 1470), (128, 539), (33, 100)])
+def test_dense_bf16_vs_oracle(N, units):
+    """ty1_dense_splitk_bf16 on bf16 operands against the fp32 matmul of the same rounded values: the products of
+    two bf16 numbers are exact in fp32, so only the summation order differs (1e-3 relative of the row scale)."""
+    rng = np.random.default_rng(N + units)
+    K = 12544
+    x = bf16_round(rng.random((N, K)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((K, units)) * 0.02).astype(np.float32))
+    wt = P.dense_to_device_layout(w)
+    part = ops.dense_splitk(dev(x, torch.bfloat16), dev(wt, torch.bfloat16), units)
+    z = part.sum(0)[:, :units].cpu().numpy()
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    np.testing.assert_allclose(z, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())

@@ -62,7 +62,7 @@ def test_flatten_is_hwc_and_dense_is_x_at_w():
 
 def test_bf16_restatement_rounds_where_the_build_rounds():
     """backbone_ref(bf16=True) states the build's bf16 network: image, conv weights and the activations between
-    layers are bf16 values (8 significant bits), the last layer's output is not rounded, and the result stays close
+    layers are bf16 values (8 significant bits) and the result stays close
     to the fp32 restatement."""
     import torch
     from yolo_amd import params as P
@@ -73,7 +73,7 @@ def test_bf16_restatement_rounds_where_the_build_rounds():
 
     def is_bf16(a):
         return np.array_equal(torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy(), a)
-    assert all(is_bf16(a) for a in acts16[:-1]) and not is_bf16(acts16[-1])
+    assert all(is_bf16(a) for a in acts16) and not is_bf16(acts32[-1])
     for a32, a16 in zip(acts32, acts16):
         assert np.abs(a16 - a32).max() <= 3e-2 * max(1.0, np.abs(a32).max())
     assert b16.shape == f32.shape

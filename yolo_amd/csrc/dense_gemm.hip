@@ -12,26 +12,31 @@
 // tails and the drained pipeline need no branches); the loop body is the software pipeline of conv_persist_kernel
 // (conv_gemm.hip): LDS store of the next chunk + re-issued fetch right after the barrier, fragments of k-block
 // kb + 1 read while kb multiplies, 8 MFMAs kept back across the barrier.
+//
+// ESZ = 2: the bf16 network (ty1_dense_splitk_bf16): x and wt are bf16, a K chunk is still 128 bytes of a row (64
+// elements) and a 16-byte fragment is the operand of ONE v_mfma_f32_32x32x16_bf16; partial sums stay fp32.
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct DenseArgs {
-    const float *x;      // [M][K]
-    const float *w;      // [units][ldk]
+    const void *x;       // [M][K]       f32 or bf16
+    const void *w;       // [units][ldk]
     float *part;         // [splits][M][ldz]
     int M, K, units, ldk, ldz;
-    int chunks_total;    // K / BK
+    int chunks_total;    // K / (elements per 128-byte chunk)
     int splits;          // gridDim.y: block (.., s) reduces chunks [chunks_total*s/splits, chunks_total*(s+1)/splits)
     int ntiles;
 };
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int ESZ = 4>
 __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    constexpr int BK = 32, NKB = BK / 8;
+    constexpr int BK = 32, NKB = BK / 8;      // BK in 4-byte units: a chunk is 128 bytes of a row
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     constexpr int LDS_STRIDE = BK + 4;
     constexpr int CPR = BK / 4, RPP = 256 / CPR;
@@ -48,19 +53,19 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
     const int piece = tid % CPR, prow = tid / CPR;
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.x), 0, (int)((long long)a.M * a.K * 4), 0x00020000);
+        const_cast<void *>(a.x), 0, (int)((long long)a.M * a.K * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(a.w), 0, (int)((long long)a.units * a.ldk * 4), 0x00020000);
+        const_cast<void *>(a.w), 0, (int)((long long)a.units * a.ldk * ESZ), 0x00020000);
     unsigned a_base[AP], b_base[BP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         const int row = p * RPP + prow, m = mt * BM + row;
-        a_base[p] = (row < BM && m < a.M) ? (unsigned)((long long)m * a.K * 4) : kOOB;
+        a_base[p] = (row < BM && m < a.M) ? (unsigned)((long long)m * a.K * ESZ) : kOOB;
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
         const int row = p * RPP + prow, n = nt * BN + row;
-        b_base[p] = (row < BN && n < a.units) ? (unsigned)((long long)n * a.ldk * 4) : kOOB;
+        b_base[p] = (row < BN && n < a.units) ? (unsigned)((long long)n * a.ldk * ESZ) : kOOB;
     }
     const int kc_begin = (int)((long long)a.chunks_total * split / a.splits);
     const int kc_end = (int)((long long)a.chunks_total * (split + 1) / a.splits);
@@ -102,31 +107,39 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
 
     const int frag_row = lane & 31, frag_k = 4 * (lane >> 5);
     const int a_row0 = wave_m * (32 * WM) + frag_row, b_row0 = wave_n * (32 * WN) + frag_row;
-    struct Frag {        // one k-block (8 k values: each lane holds 4 of them, the MFMA pairs the lane halves)
-        float a[WM][4], b[WN][4];
+    // one k-block = 32 bytes of a row; each lane holds 16 of them: 4 floats (four MFMAs of k = 2, the lane halves pair
+    // up) or 8 bf16 (one MFMA of k = 16)
+    struct Frag {
+        f32x4v a[WM], b[WN];
     };
     auto read_frag = [&](Frag &f, int buf, int kb) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(
+        for (int i = 0; i < WM; ++i)
+            f.a[i] = *reinterpret_cast<const f32x4v *>(
                 __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + kb * 8 + frag_k], 16));
-            f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
-        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(
+        for (int j = 0; j < WN; ++j)
+            f.b[j] = *reinterpret_cast<const f32x4v *>(
                 __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + kb * 8 + frag_k], 16));
-            f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
-        }
     };
+    // f32: k0..k1 of the four k pairs a fragment holds.  bf16: the fragment is one MFMA, issued with the first half.
     auto mfma = [&](const Frag &f, int k0, int k1) {
+        if constexpr (ESZ == 4) {
 #pragma unroll
-        for (int k = k0; k < k1; ++k)
+            for (int k = k0; k < k1; ++k)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+        } else if (k0 == 0) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][k], f.b[j][k], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]),
+                                                                        __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+        }
     };
 
     load_chunk();
@@ -137,13 +150,9 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
     // stores / fetches nothing real (the fetch cursor is past kc_end)
     Frag f0, f1;
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+    for (int j = 0; j < WN; ++j) f1.b[j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f1.b[j][k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f1.a[i][k] = 0.f;
+    for (int i = 0; i < WM; ++i) f1.a[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     read_frag(f0, 0, 0);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
@@ -185,40 +194,51 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int ESZ>
 int launch_dense(const char *name, DenseArgs a, int mtiles, hipStream_t s) {
     const double flops = 2.0 * a.M * (double)a.units * a.K;
-    const double bytes = 4.0 * ((double)a.M * a.K + (double)a.units * a.K + (double)a.splits * a.M * a.units);
+    const double bytes = ESZ * ((double)a.M * a.K + (double)a.units * a.K) + 4.0 * (double)a.splits * a.M * a.units;
     char tag[96];
     snprintf(tag, sizeof tag, "%s@1x%d>%d", name, a.K, a.units);
     ty1::ProfScope prof(tag, s, flops, bytes);
-    dense_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N><<<dim3(mtiles * a.ntiles, a.splits), 256, 0, s>>>(a);
+    dense_gemm_f32_kernel<WM, WN, WAVES_M, WAVES_N, ESZ><<<dim3(mtiles * a.ntiles, a.splits), 256, 0, s>>>(a);
     return ty1::check_launch(name);
+}
+
+template <int ESZ>
+int dense_dispatch(const void *x, const void *wt, float *part, int N, int K, int units, int ldk, int ldz, int splits, hipStream_t s) {
+    constexpr int CHUNK = 128 / ESZ;          // elements of K per chunk
+    TY1_REQUIRE(N >= 0 && K > 0 && units > 0 && splits > 0, "ty1_dense_splitk: bad dimensions");
+    if (N == 0) return 0;
+    TY1_REQUIRE(x && wt && part, "ty1_dense_splitk: null pointer");
+    TY1_REQUIRE(ldk >= K && (ldk * ESZ) % 16 == 0, "ty1_dense_splitk: ldk=%d must be >= K=%d with 16-byte aligned rows", ldk, K);
+    TY1_REQUIRE(ldz >= units, "ty1_dense_splitk: ldz=%d < units=%d", ldz, units);
+    TY1_REQUIRE(K % CHUNK == 0 && splits <= K / CHUNK, "ty1_dense_splitk: K=%d must be a multiple of %d and splits=%d at most K/%d",
+                K, CHUNK, splits, CHUNK);
+    TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wt & 15) == 0, "ty1_dense_splitk: x and wt must be 16-byte aligned");
+    TY1_REQUIRE((long long)N * K * ESZ < (1ll << 32) && (long long)units * ldk * ESZ < (1ll << 32),
+                "ty1_dense_splitk: operands must stay below 4 GiB each");
+    DenseArgs a{};
+    a.x = x; a.w = wt; a.part = part;
+    a.M = N; a.K = K; a.units = units; a.ldk = ldk; a.ldz = ldz;
+    a.chunks_total = K / CHUNK;
+    a.splits = splits;
+    if (N <= 32) {
+        a.ntiles = (units + 127) / 128;
+        return launch_dense<1, 1, 1, 4, ESZ>(ESZ == 4 ? "dense_f32_32x128" : "dense_bf16_32x128", a, (N + 31) / 32, s);
+    }
+    a.ntiles = (units + 63) / 64;
+    return launch_dense<1, 1, 2, 2, ESZ>(ESZ == 4 ? "dense_f32_64x64" : "dense_bf16_64x64", a, (N + 63) / 64, s);
 }
 
 }  // namespace
 
 extern "C" int ty1_dense_splitk_f32(const float *x, const float *wt, float *part, int N, int K, int units, int ldk,
                                     int ldz, int splits, ty1_stream_t stream) {
-    TY1_REQUIRE(N >= 0 && K > 0 && units > 0 && splits > 0, "ty1_dense_splitk: bad dimensions");
-    if (N == 0) return 0;
-    TY1_REQUIRE(x && wt && part, "ty1_dense_splitk: null pointer");
-    TY1_REQUIRE(ldk >= K && ldk % 4 == 0 && K % 4 == 0, "ty1_dense_splitk: ldk=%d must be >= K=%d, both multiples of 4", ldk, K);
-    TY1_REQUIRE(ldz >= units, "ty1_dense_splitk: ldz=%d < units=%d", ldz, units);
-    TY1_REQUIRE(K % 32 == 0 && splits <= K / 32, "ty1_dense_splitk: K=%d must be a multiple of 32 and splits=%d at most K/32", K, splits);
-    TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wt & 15) == 0, "ty1_dense_splitk: x and wt must be 16-byte aligned");
-    TY1_REQUIRE((long long)N * K * 4 < (1ll << 32) && (long long)units * ldk * 4 < (1ll << 32),
-                "ty1_dense_splitk: operands must stay below 4 GiB each");
-    DenseArgs a{};
-    a.x = x; a.w = wt; a.part = part;
-    a.M = N; a.K = K; a.units = units; a.ldk = ldk; a.ldz = ldz;
-    a.chunks_total = K / 32;
-    a.splits = splits;
-    hipStream_t s = (hipStream_t)stream;
-    if (N <= 32) {
-        a.ntiles = (units + 127) / 128;
-        return launch_dense<1, 1, 1, 4>("dense_f32_32x128", a, (N + 31) / 32, s);
-    }
-    a.ntiles = (units + 63) / 64;
-    return launch_dense<1, 1, 2, 2>("dense_f32_64x64", a, (N + 63) / 64, s);
+    return dense_dispatch<4>(x, wt, part, N, K, units, ldk, ldz, splits, (hipStream_t)stream);
+}
+
+extern "C" int ty1_dense_splitk_bf16(const void *x, const void *wt, float *part, int N, int K, int units, int ldk,
+                                     int ldz, int splits, ty1_stream_t stream) {
+    return dense_dispatch<2>(x, wt, part, N, K, units, ldk, ldz, splits, (hipStream_t)stream);
 }

@@ -13,9 +13,8 @@ from .params import CONV_CHANNELS, N_POOL, BN_EPS, LEAKY_ALPHA, hwio_to_ohwi, de
 
 class DeviceModel:
     def __init__(self, params, S=7, B=2, C=20, img_size=448, device='cuda:0', conv_specs=None, dtype='f32'):
-        """dtype 'f32': the reference's arithmetic.  dtype 'bf16' (BASELINE config 3): conv operands (image, weights,
-        activations between layers) in bf16 with fp32 accumulation; BN, the last conv layer's output, Dense, head
-        and decode/NMS stay fp32."""
+        """dtype 'f32': the reference's arithmetic.  dtype 'bf16' (BASELINE config 3): conv and Dense operands (image, weights,
+        activations) in bf16 with fp32 accumulation; BN, bias, head activations and decode/NMS stay fp32."""
         if dtype not in ('f32', 'bf16'):
             raise ValueError(f"dtype must be 'f32' or 'bf16', got {dtype!r}")
         self.dtype = dtype
@@ -39,6 +38,7 @@ class DeviceModel:
         self.dense_wt = torch.from_numpy(dense_to_device_layout(params['dense_w'])).to(self.device)
         self.dense_b = torch.from_numpy(np.ascontiguousarray(params['dense_b'], np.float32)).to(self.device)
         self.K = self.dense_wt.shape[1]
+        self.dense_wt_bf16 = ops.cast_bf16(self.dense_wt) if dtype == 'bf16' else None
         self._ws = {}
 
     # ------------------------------------------------------------------ workspaces
@@ -53,9 +53,8 @@ class DeviceModel:
                 scratch = max(scratch, need(N, h, h, cin, cout, pool))
                 if pool:
                     h //= 2
-                last = i == len(self.specs) - 1
-                acts.append(torch.empty((N, h, h, cout), dtype=torch.bfloat16 if bf and not last else f32, device=dev))
-            splits = ops.pick_splits(self.K, N, self.units)
+                acts.append(torch.empty((N, h, h, cout), dtype=torch.bfloat16 if bf else f32, device=dev))
+            splits = ops.pick_splits(self.K, N, self.units, chunk=64 if bf else ops.DENSE_K_ALIGN)
             ldz = ops.round_up(self.units, 4)
             slots = self.S * self.S * self.B
             ws = dict(acts=acts, scratch=torch.empty((max(scratch, 16),), dtype=torch.uint8, device=dev), part=torch.empty((splits, N, ldz), dtype=f32, device=dev),
@@ -74,7 +73,7 @@ class DeviceModel:
         for i, (layer, out) in enumerate(zip(self.conv, ws['acts'])):
             if self.dtype == 'bf16':
                 x = ops.conv3x3_bn_leaky_bf16(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA,
-                                              out_f32=i == len(self.conv) - 1, out=out, workspace=ws['scratch'])
+                                              out=out, workspace=ws['scratch'])
             else:
                 x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out,
                                          workspace=ws['scratch'])
@@ -82,7 +81,8 @@ class DeviceModel:
 
     def head(self, feats, ws=None):
         ws = ws or self.workspace(feats.shape[0])
-        part = ops.dense_splitk(feats, self.dense_wt, self.units, part=ws['part'])
+        wt = self.dense_wt_bf16 if self.dtype == 'bf16' else self.dense_wt
+        part = ops.dense_splitk(feats, wt, self.units, part=ws['part'])
         return ops.head_activate(part, self.dense_b, self.S, self.B, self.C, out=ws['y'])
 
     def predict(self, x):

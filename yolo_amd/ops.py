@@ -127,10 +127,10 @@ def preprocess_u8(img_u8, out_hw=(448, 448), swap_rb=False, out=None):
     return out
 
 
-def pick_splits(K, n_rows, units, slots=512):
+def pick_splits(K, n_rows, units, slots=512, chunk=DENSE_K_ALIGN):
     """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills whole rounds of
-    `slots` resident blocks (2 per CU), with at least 4 chunks of 32 per slice."""
-    chunks = K // DENSE_K_ALIGN
+    `slots` resident blocks (2 per CU), with at least 4 chunks (32 floats / 64 bf16 of K) per slice."""
+    chunks = K // chunk
     tiles = ((n_rows + 63) // 64) * ((units + 63) // 64) if n_rows > 32 else (units + 127) // 128
     best, best_eff = 1, 0.0
     for s in range(1, max(1, chunks // 4) + 1):
@@ -144,19 +144,20 @@ def pick_splits(K, n_rows, units, slots=512):
 
 
 def dense_splitk(x, wt, units, splits=None, part=None):
-    """x (N,K) f32, wt (rows>=units, ldk) f32 transposed Dense weight -> partials (splits,N,ldz)."""
-    _chk(x, torch.float32, 'x'); _chk(wt, torch.float32, 'wt')
+    """x (N,K), wt (rows>=units, ldk) transposed Dense weight, both f32 or both bf16 -> f32 partials (splits,N,ldz)."""
+    bf = x.dtype == torch.bfloat16
+    _chk(x, torch.bfloat16 if bf else torch.float32, 'x'); _chk(wt, x.dtype, 'wt')
     N, K = x.shape
     ldk = wt.shape[1]
     if splits is None:
-        splits = pick_splits(K, N, units)
+        splits = pick_splits(K, N, units, chunk=64 if bf else DENSE_K_ALIGN)
     ldz = round_up(units, 4)
     if part is None:
         part = torch.empty((splits, N, ldz), dtype=torch.float32, device=x.device)
     else:
         _chk(part, torch.float32, 'part')
         splits, _, ldz = part.shape
-    _lib.call('ty1_dense_splitk_f32', x.data_ptr(), wt.data_ptr(), part.data_ptr(), N, K, units, ldk, ldz,
+    _lib.call('ty1_dense_splitk_bf16' if bf else 'ty1_dense_splitk_f32', x.data_ptr(), wt.data_ptr(), part.data_ptr(), N, K, units, ldk, ldz,
               splits, _lib.current_stream())
     return part
 
