@@ -49,6 +49,12 @@ struct ConvArgs {
     float alpha;
 };
 
+#ifdef TY1_DEV_STAMPS
+#define TY1_DBG(bit) (a.dbg & (bit))
+#else
+#define TY1_DBG(bit) false
+#endif
+
 using ty1::g_stamp;
 using ty1::g_stamp_cap;
 
@@ -128,6 +134,7 @@ struct PersistArgs {
     FastDiv d_img, d_row;   // pooled layers: (H/2)*(W/2), W/2; otherwise H*W, W
     FastDiv d_splits, d_ntiles, d_mtiles, d_cpt;   // splits, ntiles, mtiles, chunks per tap
     long long *stamp;
+    int dbg;             // developer knock-outs (dev build only): 1 drop operand fetches, 2 skip LDS stores, 4 skip barriers
 };
 
 // BK counts 4-byte units of a row's K chunk (BK * 4 bytes = BKE elements of type OP); OUT_BF16: the fused epilogue
@@ -137,12 +144,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     constexpr int NTHREADS = 256;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    // LDS tiles are [row][BK] with NO padding; the 16-byte slot of a row is XOR-swizzled with the row's index in
-    // its 256-byte bank row group, which makes the ds_read_b128 16-lane groups and the 8-lane store groups
-    // conflict-free (the padded layout costs 12 % more LDS: 128x64 tiles then fit three workgroups per CU).
-    constexpr int LDS_STRIDE = BK;
-    constexpr int RB = 64 / BK;               // rows per 256-byte LDS bank row
+    // LDS image of a stage: NKB planes (one per k-block of 32 bytes of K), a plane = [BM rows of A | BN rows of B] x 32
+    // bytes + 64 bytes of padding.  A row's two 16-byte halves are swapped when bit 3 of the row index is set.  With
+    // that, a fragment read is base + kb * PLANE + 1024 * i (pure immediates: the loop computes NO LDS address; every
+    // vector instruction between two f32 MFMAs costs the matrix pipe its own issue cycles, measured 8.5 cycles per
+    // VALU op, 13 per ds_write_b128, 17 per buffer load: tools/ubench/mfma_valu.hip), the ds_read_b128 16-lane groups
+    // cover all 64 banks, and so do the 8-lane groups of the stores (plane stride = 16 banks mod 64).
     constexpr int CPR = BK / 4, RPP = NTHREADS / CPR;
+    constexpr int PLANE = (BM + BN) * 32 + 64, STAGE = (BK / 8) * PLANE;
     constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
     constexpr int NKB = BK / 8;
     constexpr int ESZ = OP::ESZ, BKE = BK * 4 / ESZ;       // element size, elements per chunk
@@ -150,8 +159,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     constexpr unsigned kOOB = 0xFFFFFFFFu;
     static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     const int chunks_per_tap = a.Cin / BKE;
     const long long x_total = (long long)a.NB * a.H * a.W * a.Cin;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * ESZ), 0x00020000);
+        const_cast<void *>(a.w), 0, TY1_DBG(1) ? 0 : (int)((long long)a.Cout * 9 * a.Cin * ESZ), 0x00020000);
 
     // ---- item descriptors (block-uniform scalars)
     struct Desc {
@@ -202,8 +210,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         return d;
     };
     // ---- per-item row geometry of this thread's fetch rows (buffer offsets relative to `origin`)
+    //      A rows: byte offset of the pixel's channel 0 (+ this thread's 16-byte piece) and the 9-bit set of taps that
+    //      fall OUTSIDE the image; B rows: byte offset of the weight row (+ piece), kOOB for rows past Cout.  The part of
+    //      an address that changes from chunk to chunk (tap shift, channel / k position) is block-uniform and travels in
+    //      the loads' scalar offset.
     struct Rows {
-        unsigned a_base[AP], a_mask[AP], b_base[BP];
+        unsigned a_off[AP], a_inv[AP], b_off[BP];
     };
     auto make_rows = [&](const Desc &d, Rows &R, long long &origin) {
         const int m_first = d.mt * BM;
@@ -214,8 +226,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             const int m = m_first + p * RPP + prow;
-            R.a_base[p] = 0;
-            R.a_mask[p] = 0;
+            R.a_off[p] = kOOB;
+            R.a_inv[p] = 0x1FFu;
             if (d.live && m < a.M && (AP * RPP == BM || p * RPP + prow < BM)) {
                 unsigned n, yy, xx;
                 if (POOL) {
@@ -232,18 +244,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                     xx = rem - yy * a.W;
                 }
                 const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - origin;
-                R.a_base[p] = (unsigned)(el * ESZ);
+                R.a_off[p] = (unsigned)(el * ESZ) + (unsigned)piece * 16u;
                 // tap t = 3*(dy+1) + (dx+1) is inside the image: product of a row condition and a column condition
                 const unsigned rows = (yy > 0 ? 0x007u : 0u) | 0x038u | ((int)yy < a.H - 1 ? 0x1C0u : 0u);
                 const unsigned cols = (xx > 0 ? 0x049u : 0u) | 0x092u | ((int)xx < a.W - 1 ? 0x124u : 0u);
-                R.a_mask[p] = rows & cols;
+                R.a_inv[p] = ~(rows & cols) & 0x1FFu;
             }
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             const int n = d.nt * BN + p * RPP + prow;
-            R.b_base[p] = (d.live && n < a.Cout && (BP * RPP == BN || p * RPP + prow < BN))
-                              ? (unsigned)((long long)n * 9 * a.Cin * ESZ) : kOOB;
+            R.b_off[p] = (d.live && n < a.Cout && (BP * RPP == BN || p * RPP + prow < BN))
+                             ? (unsigned)((long long)n * 9 * a.Cin * ESZ) + (unsigned)piece * 16u : kOOB;
         }
     };
 
@@ -287,26 +299,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[AP], rb[BP];
     int ld_round = 0, ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
-    auto load_chunk = [&]() {
-        const long long left = (x_total - org_l) * ESZ;
-        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(static_cast<const char *>(a.x)) + org_l * ESZ, 0,
-            (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
+    // One chunk fetch = scalar set-up (load_prep, SALU only) + per-row-pass loads, so that the main loop can place the
+    // passes between its MFMA groups by hand.  Vector work per load: A rows one v_bfe_i32 + one v_or (tap outside the
+    // image -> offset 0xFFFFFFFF -> the range check returns zeros), B rows none.
+    // The A descriptor is based (W+1) pixels BEFORE the first image of the item so that the scalar offset of every tap
+    // is non-negative; it is rebuilt when the cursor enters an item.
+    const int a_shift = (a.W + 1) * a.Cin * ESZ;
+    __amdgpu_buffer_rsrc_t a_rsrc;
+    auto make_a_rsrc = [&]() {
+        // (the range check of this hardware counts the scalar offset too - measured: a descriptor sized from the item
+        // origin dropped the last rows of the tensor - so the record count runs from the shifted base to the tensor end)
+        const long long left = (x_total - org_l) * ESZ + a_shift;
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(static_cast<const char *>(a.x)) + org_l * ESZ - a_shift, 0,
+            TY1_DBG(1) ? 0 : (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
+    };
+    int ld_soff_a = 0, ld_soff_b = 0;
+    auto load_prep = [&]() {
         const int t3 = ld_tap / 3;
         const int dy = t3 - 1, dx = ld_tap - 3 * t3 - 1;
-        const int delta = (((dy * a.W + dx) * a.Cin) + ld_ci0) * ESZ + piece * 16;   // bytes, may be negative
-        const unsigned tapbit = 1u << ld_tap;
+        ld_soff_a = a_shift + (((dy * a.W + dx) * a.Cin) + ld_ci0) * ESZ;
+        ld_soff_b = ld_kc * (BK * 4);
+    };
+    auto load_A = [&](int p0, int p1) {
 #pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const unsigned off = (lr.a_mask[p] & tapbit) ? lr.a_base[p] + (unsigned)delta : kOOB;
-            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, 0, 0);
-        }
-        const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
+        for (int p = p0; p < p1; ++p)
+            if (p < AP) {
+                const unsigned off = lr.a_off[p] | (unsigned)__builtin_amdgcn_sbfe((int)lr.a_inv[p], (unsigned)ld_tap, 1u);
+                ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, ld_soff_a, 0);
+            }
+    };
+    auto load_B = [&](int p0, int p1) {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const unsigned off = lr.b_base[p] == kOOB ? kOOB : lr.b_base[p] + koff;
-            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)off, 0, 0);
-        }
+        for (int p = p0; p < p1; ++p)
+            if (p < BP) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)lr.b_off[p], ld_soff_b, 0);
+    };
+    auto load_chunk = [&]() {
+        load_prep();
+        load_A(0, AP);
+        load_B(0, BP);
     };
     // Cursor step, kept apart from the loads: its branch sits at the very end of the main loop body, so that body is
     // ONE basic block and the scheduler can spread the address arithmetic and the loads between the MFMAs.
@@ -320,6 +351,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             ++ld_round;
             nxt = decode(item_of(ld_round));
             make_rows(nxt, lr, org_l);
+            make_a_rsrc();
             load_bn(nxt, sc_nxt, sh_nxt);
             ld_kc = nxt.kc0;
             ld_end = nxt.kc1;
@@ -327,17 +359,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             ld_ci0 = nxt.ci0;
         }
     };
-    auto store_chunk = [&](int buf) {
-        // RPP is a multiple of RB * CPR, so the swizzle of row p * RPP + prow does not depend on p
-        const int sp = (piece ^ ((prow / RB) & (CPR - 1))) * 4;
+    // LDS addresses (bytes).  Stores: this thread's piece of row p * RPP + prow (RPP is a multiple of 16, so the half
+    // swap does not depend on p).  `wr` points into the stage being filled, `rd_a` / `rd_b` into the stage being read;
+    // the three are stepped by +-STAGE once per chunk - the only LDS address arithmetic of the loop.
+    static_assert(RPP % 16 == 0, "half swap is periodic in the fetch pass");
+    const unsigned wr0 = (unsigned)((piece >> 1) * PLANE + prow * 32 + (((piece & 1) ^ ((prow >> 3) & 1)) << 4));
+    auto store_A = [&](unsigned wr) {
+        if (TY1_DBG(2)) return;
 #pragma unroll
         for (int p = 0; p < AP; ++p)
             if (AP * RPP == BM || p * RPP + prow < BM)
-                *reinterpret_cast<u32x4 *>(&As[buf][(p * RPP + prow) * LDS_STRIDE + sp]) = ra[p];
+                *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(&lds[wr + p * RPP * 32], 16)) = ra[p];
+    };
+    auto store_B = [&](unsigned wr) {
+        if (TY1_DBG(2)) return;
 #pragma unroll
         for (int p = 0; p < BP; ++p)
             if (BP * RPP == BN || p * RPP + prow < BN)
-                *reinterpret_cast<u32x4 *>(&Bs[buf][(p * RPP + prow) * LDS_STRIDE + sp]) = rb[p];
+                *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(&lds[wr + BM * 32 + p * RPP * 32], 16)) = rb[p];
     };
 
     f32x16 acc[WM][WN];
@@ -348,24 +387,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    static_assert(RPP % (RB * CPR) == 0 && 32 % (RB * CPR) == 0, "row swizzle is periodic in the fetch pass and the MFMA tile");
     const int frag_row = lane & 31, frag_h = lane >> 5;
     const int a_row0 = wave_m * (32 * WM) + frag_row;
     const int b_row0 = wave_n * (32 * WN) + frag_row;
-    const int a_swz = (a_row0 / RB) & (CPR - 1), b_swz = (b_row0 / RB) & (CPR - 1);
+    unsigned rd_a = (unsigned)(a_row0 * 32 + ((frag_h ^ ((a_row0 >> 3) & 1)) << 4));
+    unsigned rd_b = (unsigned)(BM * 32 + b_row0 * 32 + ((frag_h ^ ((b_row0 >> 3) & 1)) << 4));
     typedef typename OP::vec fvec;
     struct Frag {
         fvec a[WM], b[WN];
     };
-    auto read_frag = [&](Frag &f, int buf, int kb) {
+    auto read_frag = [&](Frag &f, int kb) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
-            f.a[i] = *reinterpret_cast<const fvec *>(
-                __builtin_assume_aligned(&As[buf][(a_row0 + 32 * i) * LDS_STRIDE + (((kb * 2 + frag_h) ^ a_swz) << 2)], 16));
+            f.a[i] = *reinterpret_cast<const fvec *>(__builtin_assume_aligned(&lds[rd_a + kb * PLANE + 1024 * i], 16));
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-            f.b[j] = *reinterpret_cast<const fvec *>(
-                __builtin_assume_aligned(&Bs[buf][(b_row0 + 32 * j) * LDS_STRIDE + (((kb * 2 + frag_h) ^ b_swz) << 2)], 16));
+            f.b[j] = *reinterpret_cast<const fvec *>(__builtin_assume_aligned(&lds[rd_b + kb * PLANE + 1024 * j], 16));
     };
     // f32: k0..k1 of the four k pairs a fragment holds.  bf16: the fragment is one MFMA, issued with the first half.
     auto mfma = [&](const Frag &f, int k0, int k1) {
@@ -388,6 +425,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         }
     };
     Frag f0, f1;
+    auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
+    constexpr int AH = (AP + 1) / 2, BH = (BP + 1) / 2;   // the fetch of a chunk is issued in four pieces
     auto zero_f1 = [&]() {
         const f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -402,39 +441,92 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     load_bn(cur, sc_cur, sh_cur);
 #pragma unroll
     for (int j = 0; j < WN; ++j) { sc_nxt[j] = 0.f; sh_nxt[j] = 0.f; }
+    make_a_rsrc();
     load_chunk();
     advance();
-    store_chunk(0);
+    store_A(wr0);
+    store_B(wr0);
     load_chunk();
     advance();
     __syncthreads();
     zero_f1();
-    int buf = 0;
-    read_frag(f0, 0, 0);
+    unsigned wr = wr0 + STAGE;
+    int stage_step = STAGE;                   // +STAGE, -STAGE, +STAGE ... (scalar)
+    read_frag(f0, 0);
 
     long long t_loop = 0, t_epi = 0, t_rows = 0, n_items = 0;      // developer stamps (only when a.stamp)
     while (cur.live) {
         long long t0 = 0, t1 = 0, t2 = 0;
         if (a.stamp) t0 = __builtin_amdgcn_s_memtime();
         for (int kc = cur.kc0; kc < cur.kc1; ++kc) {
-            store_chunk(buf ^ 1);                 // that buffer was last read before the previous barrier
+            // The order below is pinned with scheduling barriers: left to itself the compiler sinks the fragment reads
+            // and the chunk fetch behind the MFMAs that precede them in order to reuse their registers, which exposes
+            // one LDS round trip per k-block and leaves the fetch a fraction of a chunk instead of a whole one.
+            // Every group of WM*WN MFMAs (one k step) is followed by at most a handful of memory instructions.
+            store_A(wr);                          // that stage was last read before the previous barrier
+            SB();
+            mfma(f1, 2, 3);                       // second half of the previous chunk's last k-block (zeros at an item start)
+            SB();
+            store_B(wr);
             landed();                             // (every load older than the chunk just stored has arrived)
-            load_chunk();
-            mfma(f1, 2, 4);                       // second half of the previous chunk's last k-block (zeros at an item start)
-            read_frag(f1, buf, 1);
-            mfma(f0, 0, 4);
+            SB();
+            mfma(f1, 3, 4);
+            SB();
+            read_frag(f1, 1);
+            load_prep();
+            SB();
+            mfma(f0, 0, 1);
+            SB();
+            load_A(0, AH);
+            SB();
+            mfma(f0, 1, 2);
+            SB();
+            load_A(AH, AP);
+            SB();
+            mfma(f0, 2, 3);
+            SB();
+            load_B(0, BH);
+            SB();
+            mfma(f0, 3, 4);
+            SB();
             if (NKB == 4) {
-                read_frag(f0, buf, 2);
-                mfma(f1, 0, 4);
-                read_frag(f1, buf, 3);
-                mfma(f0, 0, 4);
+                read_frag(f0, 2);
+                SB();
+                mfma(f1, 0, 1);
+                SB();
+                load_B(BH, BP);
+                SB();
+                mfma(f1, 1, 2);
+                SB();
+                mfma(f1, 2, 3);
+                SB();
+                mfma(f1, 3, 4);
+                SB();
+                read_frag(f1, 3);
+                SB();
+                mfma(f0, 0, 1);
+                SB();
+                mfma(f0, 1, 2);
+                SB();
+                mfma(f0, 2, 3);
+                SB();
+                mfma(f0, 3, 4);
+                SB();
+            } else {
+                load_B(BH, BP);
+                SB();
             }
-            mfma(f1, 0, 2);
+            mfma(f1, 0, 1);
+            SB();
+            mfma(f1, 1, 2);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if (!TY1_DBG(4)) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            buf ^= 1;
-            read_frag(f0, buf, 0);                // first k-block of the next chunk (of the next item at an item end)
+            rd_a += stage_step;
+            rd_b += stage_step;
+            wr -= stage_step;
+            stage_step = -stage_step;
+            read_frag(f0, 0);                     // first k-block of the next chunk (of the next item at an item end)
             advance();
         }
         mfma(f1, 2, 4);
@@ -828,6 +920,8 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     }();
     const int grid = items < occ * num_cus() ? items : occ * num_cus();
     a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
+    static const char *dbg = getenv("TY1_DBG");
+    a.dbg = dbg ? atoi(dbg) : 0;
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
     const double K = 9.0 * c.Cin, out_rows = POOL ? c.M / 4.0 : (double)c.M;
     char tag[96];
