@@ -8,7 +8,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int STRIDE = 68, ROWS = 256;
 
-template <int NV, int NW, int NG>
+template <int NV, int NW, int NG, int ND = 0>
 __global__ __launch_bounds__(256, 2) void k(const float *src, float *out, int iters, const float4 *g) {
     __shared__ __attribute__((aligned(16))) float lds[ROWS * STRIDE + 4096];
     for (int i = threadIdx.x; i < ROWS * STRIDE; i += blockDim.x) lds[i] = src[i];
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256, 2) void k(const float *src, float *out, int it
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int row = lane & 31, fk = 4 * (lane >> 5);
     unsigned v0 = lane, v1 = wave;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, 16384, 0x00020000);
     f4 gl = {0, 0, 0, 0};
     const unsigned saddr = (unsigned)(size_t)((float4 *)&lds[ROWS * STRIDE] + threadIdx.x);
     for (int it = 0; it < iters; ++it) {
@@ -40,6 +41,9 @@ __global__ __launch_bounds__(256, 2) void k(const float *src, float *out, int it
 #pragma unroll
                 for (int e = 0; e < NV / 4; ++e) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v0) : "v"(v1));
                 if (q < NW) asm volatile("ds_write_b128 %0, %1" ::"v"(saddr), "v"(gl) : "memory");
+                if (q < ND) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(lds + ROWS * STRIDE + 256 * wave), 16, (lane * 16 + v1 * 1024) & 16383, 0, 0, 0);
+                }
                 if (q < NG) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gl) : "v"(g + ((v1 * 64 + lane) & 1023)) : "memory");
             }
         }
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void k(const float *src, float *out, int it
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + v0 + gl.x;
 }
 
-template <int NV, int NW, int NG>
+template <int NV, int NW, int NG, int ND = 0>
 void run(const float *src, const float4 *g, double seconds) {
     const int blocks = 512, iters = 1024;
     float *out;
@@ -60,13 +64,13 @@ void run(const float *src, const float4 *g, double seconds) {
     float ms = 0, best = 1e9; double total = 0;
     while (total < seconds * 1e3) {
         (void)hipEventRecord(e0);
-        k<NV, NW, NG><<<blocks, 256>>>(src, out, iters, g);
+        k<NV, NW, NG, ND><<<blocks, 256>>>(src, out, iters, g);
         (void)hipEventRecord(e1);
         (void)hipDeviceSynchronize();
         (void)hipEventElapsedTime(&ms, e0, e1);
         total += ms; if (ms < best) best = ms;
     }
-    printf("per 16 MFMAs: %2d VALU %d ds_write_b128 %d global_load_x4 : last %.3f ms %.1f TFLOP/s (best %.1f)\n", NV, NW, NG, ms,
+    printf("per 16 MFMAs: %2d VALU %d ds_write_b128 %d global_load_x4 %d buffer_load_lds_x4: last %.3f ms %.1f TFLOP/s (best %.1f)\n", NV, NW, NG, ND, ms,
            flop / (ms * 1e-3) / 1e12, flop / (best * 1e-3) / 1e12);
     (void)hipFree(out);
 }
@@ -91,5 +95,8 @@ int main(int argc, char **argv) {
     run<0, 0, 2>(d, g, secs);
     run<0, 0, 4>(d, g, secs);
     run<12, 2, 2>(d, g, secs);
+    run<0, 0, 0, 1>(d, g, secs);
+    run<0, 0, 0, 2>(d, g, secs);
+    run<0, 0, 0, 4>(d, g, secs);
     return 0;
 }

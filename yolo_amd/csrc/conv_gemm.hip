@@ -150,10 +150,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     // vector instruction between two f32 MFMAs costs the matrix pipe its own issue cycles, measured 8.5 cycles per
     // VALU op, 13 per ds_write_b128, 17 per buffer load: tools/ubench/mfma_valu.hip), the ds_read_b128 16-lane groups
     // cover all 64 banks, and so do the 8-lane groups of the stores (plane stride = 16 banks mod 64).
-    constexpr int CPR = BK / 4, RPP = NTHREADS / CPR;
     constexpr int PLANE = (BM + BN) * 32 + 64, STAGE = (BK / 8) * PLANE;
-    constexpr int AP = (BM + RPP - 1) / RPP, BP = (BN + RPP - 1) / RPP;
     constexpr int NKB = BK / 8;
+    // Operand fetch is LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, and - unlike a load
+    // into VGPRs (17 cycles) or a ds_write_b128 (13) - no cost to the matrix pipe.  One wave-instruction fills 1 KiB =
+    // 32 rows of one plane (lane l: row l/2, 16-byte half l&1).  The (BM/32 + BN/32) * NKB pieces of a chunk are dealt to
+    // the four waves so that a wave keeps to its own row groups: piece q = wave + 4t -> row group q % G, plane q / G.
+    constexpr int GA = BM / 32, GB = BN / 32;                          // row groups
+    constexpr int NGA = GA >= 4 ? GA / 4 : 1, NGB = GB >= 4 ? GB / 4 : 1;   // row groups a wave touches
+    constexpr int TA = (GA * NKB + 3) / 4, TB = (GB * NKB + 3) / 4;   // pieces per wave and chunk
     constexpr int ESZ = OP::ESZ, BKE = BK * 4 / ESZ;       // element size, elements per chunk
     constexpr int OSZ = OUT_BF16 ? 2 : 4;                  // bytes per output element
     constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int piece = tid % CPR, prow = tid / CPR;
+    const int dma_row = lane >> 1, dma_half = (lane & 1) ^ ((lane >> 4) & 1);   // logical half this lane fetches
     const int G = gridDim.x;
     const int items = a.whole + a.rem * a.splits;
     if (a.stamp && tid == 0) {
@@ -210,12 +215,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         return d;
     };
     // ---- per-item row geometry of this thread's fetch rows (buffer offsets relative to `origin`)
-    //      A rows: byte offset of the pixel's channel 0 (+ this thread's 16-byte piece) and the 9-bit set of taps that
-    //      fall OUTSIDE the image; B rows: byte offset of the weight row (+ piece), kOOB for rows past Cout.  The part of
+    //      A rows: byte offset of the pixel's channel 0 (+ this lane's 16-byte half) and the 9-bit set of taps that
+    //      fall OUTSIDE the image; B rows: byte offset of the weight row (+ half), kOOB for rows past Cout.  The part of
     //      an address that changes from chunk to chunk (tap shift, channel / k position) is block-uniform and travels in
     //      the loads' scalar offset.
     struct Rows {
-        unsigned a_off[AP], a_inv[AP], b_off[BP];
+        unsigned a_off[NGA], a_inv[NGA], b_off[NGB];
     };
     auto make_rows = [&](const Desc &d, Rows &R, long long &origin) {
         const int m_first = d.mt * BM;
@@ -224,11 +229,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             origin = (long long)img * a.H * a.W * a.Cin;
         }
 #pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            const int m = m_first + p * RPP + prow;
+        for (int p = 0; p < NGA; ++p) {
+            const int m = m_first + 32 * (GA >= 4 ? wave + 4 * p : wave % GA) + dma_row;
             R.a_off[p] = kOOB;
             R.a_inv[p] = 0x1FFu;
-            if (d.live && m < a.M && (AP * RPP == BM || p * RPP + prow < BM)) {
+            if (d.live && m < a.M) {
                 unsigned n, yy, xx;
                 if (POOL) {
                     const unsigned win = (unsigned)m >> 2, q = m & 3;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                     xx = rem - yy * a.W;
                 }
                 const long long el = (((long long)n * a.H + yy) * a.W + xx) * a.Cin - origin;
-                R.a_off[p] = (unsigned)(el * ESZ) + (unsigned)piece * 16u;
+                R.a_off[p] = (unsigned)(el * ESZ) + (unsigned)dma_half * 16u;
                 // tap t = 3*(dy+1) + (dx+1) is inside the image: product of a row condition and a column condition
                 const unsigned rows = (yy > 0 ? 0x007u : 0u) | 0x038u | ((int)yy < a.H - 1 ? 0x1C0u : 0u);
                 const unsigned cols = (xx > 0 ? 0x049u : 0u) | 0x092u | ((int)xx < a.W - 1 ? 0x124u : 0u);
@@ -252,10 +257,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             }
         }
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            const int n = d.nt * BN + p * RPP + prow;
-            R.b_off[p] = (d.live && n < a.Cout && (BP * RPP == BN || p * RPP + prow < BN))
-                             ? (unsigned)((long long)n * 9 * a.Cin * ESZ) + (unsigned)piece * 16u : kOOB;
+        for (int p = 0; p < NGB; ++p) {
+            const int n = d.nt * BN + 32 * (GB >= 4 ? wave + 4 * p : wave % GB) + dma_row;
+            R.b_off[p] = (d.live && n < a.Cout) ? (unsigned)((long long)n * 9 * a.Cin * ESZ) + (unsigned)dma_half * 16u : kOOB;
         }
     };
 
@@ -276,9 +280,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     make_rows(cur, lr, org_l);
 
     // ---- BN scale / shift of an item's channels (lane holds channel lane&31 of each tile column).  They are
-    //      fetched when the fetch cursor ENTERS the item, i.e. two chunks before its MFMAs start, and the per-chunk
-    //      LDS store that follows in every iteration marks them as arrived (see `landed` below): the epilogue then
-    //      needs no vmcnt wait of its own, which would also wait for the chunk prefetches in flight.
+    //      fetched when the fetch cursor ENTERS the item, i.e. a chunk before its MFMAs start.
     float sc_cur[WN], sh_cur[WN], sc_nxt[WN], sh_nxt[WN];
     auto load_bn = [&](const Desc &d, float (&sc)[WN], float (&sh)[WN]) {
 #pragma unroll
@@ -289,19 +291,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             sh[j] = ok ? a.shift[n] : 0.f;
         }
     };
-    auto landed = [&]() {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(sc_nxt[j]), "+v"(sh_nxt[j]));
-    };
 
     // ---- fetch cursor: two chunks ahead of the MFMAs.  When it reaches the end of its item it moves on to this
     //      block's next item (a block-uniform branch taken once per item: new descriptor, new row geometry).
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[AP], rb[BP];
     int ld_round = 0, ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
-    // One chunk fetch = scalar set-up (load_prep, SALU only) + per-row-pass loads, so that the main loop can place the
-    // passes between its MFMA groups by hand.  Vector work per load: A rows one v_bfe_i32 + one v_or (tap outside the
-    // image -> offset 0xFFFFFFFF -> the range check returns zeros), B rows none.
+    // One chunk fetch = scalar set-up (SALU) + the tap mask of this wave's A rows (one v_bfe_i32 + one v_or per row
+    // group: tap outside the image -> offset 0xFFFFFFFF -> the range check makes the DMA write zeros) + TA + TB DMA
+    // instructions whose destination (stage, plane, row group) is a scalar in M0.
     // The A descriptor is based (W+1) pixels BEFORE the first image of the item so that the scalar offset of every tap
     // is non-negative; it is rebuilt when the cursor enters an item.
     const int a_shift = (a.W + 1) * a.Cin * ESZ;
@@ -315,29 +311,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             TY1_DBG(1) ? 0 : (int)(left > 0xFFFFFFFFll ? 0xFFFFFFFFll : left), 0x00020000);
     };
     int ld_soff_a = 0, ld_soff_b = 0;
+    unsigned a_moff[NGA];
     auto load_prep = [&]() {
         const int t3 = ld_tap / 3;
         const int dy = t3 - 1, dx = ld_tap - 3 * t3 - 1;
         ld_soff_a = a_shift + (((dy * a.W + dx) * a.Cin) + ld_ci0) * ESZ;
         ld_soff_b = ld_kc * (BK * 4);
-    };
-    auto load_A = [&](int p0, int p1) {
 #pragma unroll
-        for (int p = p0; p < p1; ++p)
-            if (p < AP) {
-                const unsigned off = lr.a_off[p] | (unsigned)__builtin_amdgcn_sbfe((int)lr.a_inv[p], (unsigned)ld_tap, 1u);
-                ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)off, ld_soff_a, 0);
+        for (int p = 0; p < NGA; ++p)
+            a_moff[p] = lr.a_off[p] | (unsigned)__builtin_amdgcn_sbfe((int)lr.a_inv[p], (unsigned)ld_tap, 1u);
+    };
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto dma_A = [&](int stage_off, int t0, int t1) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+            if (t < TA && (4 * t + 3 < GA * NKB || wave + 4 * t < GA * NKB)) {
+                const int q = wave + 4 * t, g = q % GA, kb = q / GA;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr)(lds + stage_off + kb * PLANE + g * 1024), 16,
+                                                         (int)a_moff[GA >= 4 ? t % NGA : 0], ld_soff_a + kb * 32, 0, 0);
             }
     };
-    auto load_B = [&](int p0, int p1) {
+    auto dma_B = [&](int stage_off, int t0, int t1) {
 #pragma unroll
-        for (int p = p0; p < p1; ++p)
-            if (p < BP) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)lr.b_off[p], ld_soff_b, 0);
-    };
-    auto load_chunk = [&]() {
-        load_prep();
-        load_A(0, AP);
-        load_B(0, BP);
+        for (int t = t0; t < t1; ++t)
+            if (t < TB && (4 * t + 3 < GB * NKB || wave + 4 * t < GB * NKB)) {
+                const int q = wave + 4 * t, g = q % GB, kb = q / GB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr)(lds + stage_off + kb * PLANE + (BM + 32 * g) * 32), 16,
+                                                         (int)lr.b_off[GB >= 4 ? t % NGB : 0], ld_soff_b + kb * 32, 0, 0);
+            }
     };
     // Cursor step, kept apart from the loads: its branch sits at the very end of the main loop body, so that body is
     // ONE basic block and the scheduler can spread the address arithmetic and the loads between the MFMAs.
@@ -359,26 +360,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             ld_ci0 = nxt.ci0;
         }
     };
-    // LDS addresses (bytes).  Stores: this thread's piece of row p * RPP + prow (RPP is a multiple of 16, so the half
-    // swap does not depend on p).  `wr` points into the stage being filled, `rd_a` / `rd_b` into the stage being read;
-    // the three are stepped by +-STAGE once per chunk - the only LDS address arithmetic of the loop.
-    static_assert(RPP % 16 == 0, "half swap is periodic in the fetch pass");
-    const unsigned wr0 = (unsigned)((piece >> 1) * PLANE + prow * 32 + (((piece & 1) ^ ((prow >> 3) & 1)) << 4));
-    auto store_A = [&](unsigned wr) {
-        if (TY1_DBG(2)) return;
-#pragma unroll
-        for (int p = 0; p < AP; ++p)
-            if (AP * RPP == BM || p * RPP + prow < BM)
-                *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(&lds[wr + p * RPP * 32], 16)) = ra[p];
-    };
-    auto store_B = [&](unsigned wr) {
-        if (TY1_DBG(2)) return;
-#pragma unroll
-        for (int p = 0; p < BP; ++p)
-            if (BP * RPP == BN || p * RPP + prow < BN)
-                *reinterpret_cast<u32x4 *>(__builtin_assume_aligned(&lds[wr + BM * 32 + p * RPP * 32], 16)) = rb[p];
-    };
-
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -426,7 +407,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     };
     Frag f0, f1;
     auto SB = [] { __builtin_amdgcn_sched_barrier(0); };
-    constexpr int AH = (AP + 1) / 2, BH = (BP + 1) / 2;   // the fetch of a chunk is issued in four pieces
+    constexpr int AH = (TA + 1) / 2, BH = (TB + 1) / 2;   // the fetch of a chunk is issued in four pieces
     auto zero_f1 = [&]() {
         const f32x4v z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -442,15 +423,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
     for (int j = 0; j < WN; ++j) { sc_nxt[j] = 0.f; sh_nxt[j] = 0.f; }
     make_a_rsrc();
-    load_chunk();
+    load_prep();
+    dma_A(0, 0, TA);
+    dma_B(0, 0, TB);
     advance();
-    store_A(wr0);
-    store_B(wr0);
-    load_chunk();
-    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     zero_f1();
-    unsigned wr = wr0 + STAGE;
+    int wr = STAGE;                           // stage being filled (scalar byte offset)
     int stage_step = STAGE;                   // +STAGE, -STAGE, +STAGE ... (scalar)
     read_frag(f0, 0);
 
@@ -460,32 +440,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         if (a.stamp) t0 = __builtin_amdgcn_s_memtime();
         for (int kc = cur.kc0; kc < cur.kc1; ++kc) {
             // The order below is pinned with scheduling barriers: left to itself the compiler sinks the fragment reads
-            // and the chunk fetch behind the MFMAs that precede them in order to reuse their registers, which exposes
-            // one LDS round trip per k-block and leaves the fetch a fraction of a chunk instead of a whole one.
-            // Every group of WM*WN MFMAs (one k step) is followed by at most a handful of memory instructions.
-            store_A(wr);                          // that stage was last read before the previous barrier
+            // behind the MFMAs that precede them in order to reuse their registers, which exposes one LDS round trip
+            // per k-block.  The fetch of the NEXT chunk goes out first: the stage it fills was last read before the
+            // barrier that ended the previous iteration, and it has this whole chunk to land.
+            load_prep();
+            SB();
+            dma_A(wr, 0, AH);
             SB();
             mfma(f1, 2, 3);                       // second half of the previous chunk's last k-block (zeros at an item start)
             SB();
-            store_B(wr);
-            landed();                             // (every load older than the chunk just stored has arrived)
+            dma_A(wr, AH, TA);
             SB();
             mfma(f1, 3, 4);
             SB();
             read_frag(f1, 1);
-            load_prep();
             SB();
             mfma(f0, 0, 1);
             SB();
-            load_A(0, AH);
+            dma_B(wr, 0, BH);
             SB();
             mfma(f0, 1, 2);
             SB();
-            load_A(AH, AP);
+            dma_B(wr, BH, TB);
             SB();
             mfma(f0, 2, 3);
-            SB();
-            load_B(0, BH);
             SB();
             mfma(f0, 3, 4);
             SB();
@@ -493,8 +471,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                 read_frag(f0, 2);
                 SB();
                 mfma(f1, 0, 1);
-                SB();
-                load_B(BH, BP);
                 SB();
                 mfma(f1, 1, 2);
                 SB();
@@ -512,13 +488,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                 SB();
                 mfma(f0, 3, 4);
                 SB();
-            } else {
-                load_B(BH, BP);
-                SB();
             }
             mfma(f1, 0, 1);
             SB();
             mfma(f1, 1, 2);
+            // every wave waits for its own DMA pieces, the barrier then publishes the whole stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (!TY1_DBG(4)) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
