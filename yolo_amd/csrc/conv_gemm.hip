@@ -49,6 +49,9 @@ struct ConvArgs {
     float alpha;
 };
 
+#ifndef TY1_NS3_LIMIT
+#define TY1_NS3_LIMIT (80 * 1024)
+#endif
 #ifdef TY1_DEV_STAMPS
 #define TY1_DBG(bit) (a.dbg & (bit))
 #else
@@ -69,7 +72,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------
 // Persistent conv kernel.  The grid is two workgroups per CU; workgroup b walks the work items
 // slot(b), slot(b) + G, slot(b) + 2G ... (item = output tile x K-split piece) as ONE continuous stream of
-// K chunks: the fetch cursor runs two chunks ahead of the MFMAs and simply crosses into the next item,
+// K chunks: the fetch cursor runs NS-1 chunks ahead of the MFMAs and simply crosses into the next item,
 // so a new tile starts with its operands already in LDS - no per-tile prologue (address arithmetic +
 // an exposed HBM round trip, 4-10 us per tile when every tile was its own workgroup) and no drain.
 // Row geometry (image, y, x of every GEMM row of a tile, 3x3 validity mask) is recomputed per item with
@@ -134,7 +137,7 @@ struct PersistArgs {
     FastDiv d_img, d_row;   // pooled layers: (H/2)*(W/2), W/2; otherwise H*W, W
     FastDiv d_splits, d_ntiles, d_mtiles, d_cpt;   // splits, ntiles, mtiles, chunks per tap
     long long *stamp;
-    int dbg;             // developer knock-outs (dev build only): 1 drop operand fetches, 2 skip LDS stores, 4 skip barriers
+    int dbg;             // developer knock-outs (dev build only): 1 drop A fetches, 8 drop B fetches, 4 skip barriers, 16 coalesced (wrong) fetch pattern
 };
 
 // BK counts 4-byte units of a row's K chunk (BK * 4 bytes = BKE elements of type OP); OUT_BF16: the fused epilogue
@@ -164,11 +167,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     constexpr unsigned kOOB = 0xFFFFFFFFu;
     static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    // NS stages: the fetch cursor runs NS-1 chunks ahead of the MFMAs.  Three where that keeps two workgroups on a CU
+    // (a chunk of a small tile is too short to cover an L2 miss), else two.
+    constexpr int NS = 3 * STAGE <= TY1_NS3_LIMIT ? 3 : 2;
+    constexpr int PW = TA + TB;                 // DMA instructions per wave and chunk
+    __shared__ __attribute__((aligned(16))) char lds[NS * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int dma_row = lane >> 1, dma_half = (lane & 1) ^ ((lane >> 4) & 1);   // logical half this lane fetches
+    // (dev knock-out 16: timing-only fetch pattern of 8 rows x 128 contiguous bytes per DMA instruction)
+    const int dma_row = TY1_DBG(16) ? lane >> 3 : lane >> 1;
+    const int dma_half = TY1_DBG(16) ? (lane & 7) : (lane & 1) ^ ((lane >> 4) & 1);   // logical half this lane fetches
     const int G = gridDim.x;
     const int items = a.whole + a.rem * a.splits;
     if (a.stamp && tid == 0) {
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     const int chunks_per_tap = a.Cin / BKE;
     const long long x_total = (long long)a.NB * a.H * a.W * a.Cin;
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void *>(a.w), 0, TY1_DBG(1) ? 0 : (int)((long long)a.Cout * 9 * a.Cin * ESZ), 0x00020000);
+        const_cast<void *>(a.w), 0, TY1_DBG(8) ? 0 : (int)((long long)a.Cout * 9 * a.Cin * ESZ), 0x00020000);
 
     // ---- item descriptors (block-uniform scalars)
     struct Desc {
@@ -292,7 +301,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         }
     };
 
-    // ---- fetch cursor: two chunks ahead of the MFMAs.  When it reaches the end of its item it moves on to this
+    // (marker: tells the compiler that sc_nxt / sh_nxt are needed here, right after the per-chunk wait, where its own
+    //  wait for them costs nothing; without it the wait would sit in the epilogue and drain the fetches in flight)
+    auto landed = [&]() {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(sc_nxt[j]), "+v"(sh_nxt[j]));
+    };
+
+    // ---- fetch cursor: NS-1 chunks ahead of the MFMAs.  When it reaches the end of its item it moves on to this
     //      block's next item (a block-uniform branch taken once per item: new descriptor, new row geometry).
     int ld_round = 0, ld_kc = cur.kc0, ld_end = cur.kc1, ld_tap = cur.tap0, ld_ci0 = cur.ci0;
     // One chunk fetch = scalar set-up (SALU) + the tap mask of this wave's A rows (one v_bfe_i32 + one v_or per row
@@ -423,15 +439,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
     for (int j = 0; j < WN; ++j) { sc_nxt[j] = 0.f; sh_nxt[j] = 0.f; }
     make_a_rsrc();
-    load_prep();
-    dma_A(0, 0, TA);
-    dma_B(0, 0, TB);
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) {
+        load_prep();
+        dma_A(st * STAGE, 0, TA);
+        dma_B(st * STAGE, 0, TB);
+        advance();
+    }
+    // wait for the first chunk only: the PW * (NS - 2) newest DMAs of this wave may stay in flight
+    // (a raw barrier: __syncthreads() would drain every DMA in flight - its fence waits vmcnt(0) - and there are no
+    //  ds_writes to publish; lgkmcnt(0) retires this wave's reads of the stage that the others refill next)
+    auto wg_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wait_chunk = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NS - 2)) : "memory"); };
+    wait_chunk();
+    wg_barrier();
     zero_f1();
-    int wr = STAGE;                           // stage being filled (scalar byte offset)
-    int stage_step = STAGE;                   // +STAGE, -STAGE, +STAGE ... (scalar)
+    int wr = (NS - 1) * STAGE;                // stage being filled (scalar byte offset)
+    int rd_stage = 0;                         // stage being read
     read_frag(f0, 0);
 
     long long t_loop = 0, t_epi = 0, t_rows = 0, n_items = 0;      // developer stamps (only when a.stamp)
@@ -492,15 +516,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
             mfma(f1, 0, 1);
             SB();
             mfma(f1, 1, 2);
-            // every wave waits for its own DMA pieces, the barrier then publishes the whole stage
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave waits for its own DMA pieces of the next chunk, the barrier then publishes that stage
+            wait_chunk();
+            landed();
             __builtin_amdgcn_sched_barrier(0);
-            if (!TY1_DBG(4)) __syncthreads();
+            if (!TY1_DBG(4)) wg_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            rd_a += stage_step;
-            rd_b += stage_step;
-            wr -= stage_step;
-            stage_step = -stage_step;
+            {                                     // ring step: scalar except the two fragment read bases
+                wr = rd_stage * STAGE;            // the stage just read is the next one to fill
+                const bool wrap = rd_stage == NS - 1;
+                const int step = wrap ? -(NS - 1) * STAGE : STAGE;
+                rd_stage = wrap ? 0 : rd_stage + 1;
+                rd_a += step;
+                rd_b += step;
+            }
             read_frag(f0, 0);                     // first k-block of the next chunk (of the next item at an item end)
             advance();
         }
@@ -582,7 +611,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         zero_f1();
         if (a.stamp) t2 = __builtin_amdgcn_s_memtime();
 
-        // ---- next item becomes current; the fetch cursor is already two chunks inside it
+        // ---- next item becomes current; the fetch cursor is already NS-1 chunks inside it
         cur = nxt;
 #pragma unroll
         for (int j = 0; j < WN; ++j) { sc_cur[j] = sc_nxt[j]; sh_cur[j] = sh_nxt[j]; }
