@@ -63,8 +63,8 @@ def cpu_baseline(prm, x_cpu, seconds, C=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample: seconds of host work to time')
     ap.add_argument('--no-cpu-baseline', action='store_true')

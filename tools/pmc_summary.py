@@ -24,3 +24,12 @@ for k, v in sorted(agg.items()):
         row['mfma_busy_frac'] = row['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (row['GRBM_GUI_ACTIVE'] / 8)
     out[k] = row
 print(json.dumps(out, indent=1))
+if len(sys.argv) > 3 and sys.argv[2] == '--traffic':      # also write the per-launch HBM bytes bench.py quotes (profiles/pmc_traffic.json)
+    tag = os.path.basename(os.path.normpath(root))
+    tr = {'source': f'profiles/{tag}_bench_b64_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per '
+                    'MI355X_MICROARCH.md HBM section)', 'kernels': {}}
+    for k, row in out.items():
+        if 'hbm_read_MB' in row and 'hbm_write_MB' in row:
+            tr['kernels'][k] = {'hbm_read_bytes': row['hbm_read_MB'] * 1048576, 'hbm_write_bytes': row['hbm_write_MB'] * 1048576,
+                                'mfma_busy_frac': row.get('mfma_busy_frac', 0.0)}
+    json.dump(tr, open(sys.argv[3], 'w'), indent=1)

@@ -51,6 +51,13 @@ if args.persist:
     print(f'persistent blocks {len(b)}  span {end.max():.1f} us  items/block min {ni.min():.0f} max {ni.max():.0f}')
     print(f'per item (shader cycles): loop {np.mean(b[:, 1] / ni):.0f}  epilogue {np.mean(b[:, 2] / ni):.0f}  rows {np.mean(b[:, 6] / ni):.0f}'
           f'   block time {np.mean(end - st):.1f} us -> {np.mean((end - st) / ni):.2f} us per item')
+    print(f'shader clock while a block runs (stamped cycles / block time): {np.mean((b[:, 1] + b[:, 2] + b[:, 6]) / np.maximum(end - st, 1e-9)) / 1e3:.3f} GHz')
+    tr = ball[1024:1024 + 64]
+    tr = tr[tr[:, 1] != 0]
+    if len(tr) > 2:
+        ck = np.diff(tr[:, 0]) / np.diff(tr[:, 1]) * 0.1
+        print('block 0: item end times (us)', np.round((tr[1:, 1] - t0) / 100.0).astype(int).tolist())
+        print('block 0: shader clock per item (GHz)', np.round(ck, 2).tolist())
     print('end-time histogram:', np.histogram(end, bins=8)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
     hw = b[:, 4]; xcc = b[:, 5] & 0xF
     cuid = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)

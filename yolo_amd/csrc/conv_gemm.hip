@@ -145,7 +145,6 @@ struct PersistArgs {
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool POOL, typename OP = OpF32, bool OUT_BF16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel(const PersistArgs a) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    constexpr int NTHREADS = 256;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     // LDS image of a stage: NKB planes (one per k-block of 32 bytes of K), a plane = [BM rows of A | BN rows of B] x 32
     // bytes + 64 bytes of padding.  A row's two 16-byte halves are swapped when bit 3 of the row index is set.  With
@@ -564,6 +563,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                 static_cast<char *>(a.y) + (long long)r0 * a.Cout * OSZ, 0,
                 (int)(obytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : obytes), 0x00020000);
             const unsigned row_bytes = (unsigned)a.Cout * (unsigned)OSZ;
+            const bool pool_first = a.alpha >= 0.f;
             auto put = [&](float v, unsigned off) {
                 if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
                 else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
@@ -578,13 +578,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
+                            // LeakyReLU with alpha >= 0 is non-decreasing, so it commutes with the window maximum:
+                            // pool the four BN outputs first, activate once (bit-identical; alpha < 0 keeps the
+                            // reference order).  Every VALU instruction here costs the co-resident workgroup
+                            // matrix-pipe cycles.
                             float v[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float t = acc[i][j][4 * g + q] * sc_cur[j] + sh_cur[j];
-                                v[q] = t > 0.f ? t : t * a.alpha;
+                            for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] * sc_cur[j] + sh_cur[j];
+                            float pooled;
+                            if (pool_first) {
+                                const float t = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                                pooled = t > 0.f ? t : t * a.alpha;
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * a.alpha;
+                                pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                             }
-                            const float pooled = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                             const unsigned off = n_ok ? vb + (unsigned)(8 * i + 2 * g) * row_bytes : kOOB;
                             put(pooled, off);
                         }
@@ -618,6 +627,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         if (a.stamp) {
             const long long t3 = __builtin_amdgcn_s_memtime();
             t_loop += t1 - t0; t_epi += t2 - t1; t_rows += t3 - t2; ++n_items;
+            if (tid == 0 && blockIdx.x < 8 && n_items < 64) {     // per-item clock trace of the first blocks (rows 1024...)
+                a.stamp[(1024 + blockIdx.x * 64 + n_items) * 8 + 0] = t3;
+                a.stamp[(1024 + blockIdx.x * 64 + n_items) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            }
         }
     }
     if (a.stamp && tid == 0) {
