@@ -29,8 +29,8 @@ PEAK_HBM_GBS = 8000.0
 _CFG = {'128x128': '2, 2, 2, 2, 32', '128x64': '2, 1, 2, 2, 32', '64x64': '1, 1, 2, 2, 32', '256x32': '2, 1, 4, 1, 32',
         'bk16_128x64': '2, 1, 2, 2, 16', 'bk16_256x32': '2, 1, 4, 1, 16'}
 ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv3x3_c16_pool': 'conv3x3_c16_kernel<true, 1>',
-                  'dense_f32_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2>',
-                  'dense_f32_32x128': 'dense_gemm_f32_kernel<1, 1, 1, 4>',
+                  'dense_f32_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2, 4>',
+                  'dense_f32_32x128': 'dense_gemm_f32_kernel<1, 1, 1, 4, 4>',
                   'decode_nms': 'decode_nms_kernel<2>', 'head_activate': 'head_activate_kernel'}
 for _k, _v in _CFG.items():
     ROCPROF_SYMBOL[f'conv_f32_{_k}_pool'] = f'conv_persist_kernel<{_v}, true, OpF32, false>'
