@@ -21,8 +21,6 @@
 // Two workgroups (2 x 29.4 KB of LDS each) share a CU.
 #include "common.h"
 
-#include <type_traits>
-
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -119,32 +117,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     const unsigned out_lane = POOL ? (unsigned)wave * row_b + (unsigned)h * px_b + (unsigned)col * 4u
                                    : (unsigned)(2 * wave) * row_b + (unsigned)(2 * h) * px_b + (unsigned)col * 4u;
     const long long y_total = (long long)NB * Ho * Wo * Cout;
-    // piece idx = 4u + gq of patch (n, y0, x0); n < 0: nothing is stored.  A patch that lies wholly inside the image
-    // (every patch of the network's layer) takes the branch without per-store tests: the piece part of the offset goes
-    // into the store's scalar offset, so a store costs no vector instruction besides itself (each one would cost the
-    // matrix pipe ~8 cycles: DESIGN.md 4.1).
-    // output descriptor + edge state of a patch, computed once per patch from block-uniform values
-    struct OutDesc {
-        __amdgpu_buffer_rsrc_t rsrc;
-        bool full;
-        int rows_left, cols_left;
-    };
-    auto out_desc = [&](int n, int y0, int x0) {
-        OutDesc d;
+    // piece idx = 4u + gq of patch (n, y0, x0); n < 0: nothing is stored
+    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], int n, int y0, int x0) {
+        const int u = idx >> 2, gq = idx & 3;
         const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
         const long long o_org = n < 0 ? 0ll : (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
         const long long o_left = n < 0 ? 0ll : (y_total - o_org) * 4;
-        d.rsrc = __builtin_amdgcn_make_buffer_rsrc(y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
-        d.full = y0 + TH <= H && x0 + TW <= W;               // block-uniform
-        d.rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
-        d.cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
-        return d;
-    };
-    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], const OutDesc &od) {
-        const int u = idx >> 2, gq = idx & 3;
-        const __amdgpu_buffer_rsrc_t o_rsrc = od.rsrc;
-        const bool full = od.full;
-        const int rows_left = od.rows_left, cols_left = od.cols_left;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        const int rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
+        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float z[4];
@@ -154,42 +136,44 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
                 // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
                 const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
                 const float v = m > 0.f ? m : m * alpha;
-                const int piece_off = (8 * u + 2 * gq) * (int)px_b + 128 * nt;
-                if (full) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)out_lane, piece_off, 0);
-                } else {
-                    const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)(ok ? out_lane + (unsigned)piece_off : kOOB), 0, 0);
-                }
+                const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
+                const unsigned off = ok ? out_lane + (unsigned)(8 * u + 2 * gq) * px_b + 128u * nt : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
                     const int dy = r >> 1, dx = 2 * (8 * u + 2 * gq) + (r & 1);
-                    const int piece_off = dy * (int)row_b + dx * (int)px_b + 128 * nt;
-                    if (full) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)out_lane, piece_off, 0);
-                    } else {
-                        const bool ok = dy < rows_left && dx < cols_left;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)(ok ? out_lane + (unsigned)piece_off : kOOB), 0, 0);
-                    }
+                    const bool ok = dy < rows_left && dx < cols_left;
+                    const unsigned off = ok ? out_lane + (unsigned)dy * row_b + (unsigned)dx * px_b + 128u * nt : kOOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
                 }
             }
         }
     };
 
-    // One pipeline step = one patch: fetch the next halo, multiply this one (buffer BUF) into `cur`, and - with one channel
-    // tile per wave (PIPE) - issue the epilogue of the PREVIOUS patch, whose accumulators are `prv`, between the taps.
-    // The loop below alternates two accumulator sets, so nothing is copied or cleared: a patch's first MFMA takes C = 0.
+    // With one channel tile per wave there are registers for a second accumulator set: the epilogue of a patch is
+    // then issued between the MFMAs of the NEXT patch (one piece per tap) instead of after its own.
     constexpr bool PIPE = NT == 1;
-    OutDesc pod = out_desc(-1, 0, 0);
-    bool have_prev = false;
-    auto step = [&](auto buf_c, f32x16 (&cur)[2][NT], const f32x16 (&prv)[2][NT], int p) {
-        constexpr int BUF = decltype(buf_c)::value;
+    f32x16 acc[2][NT], prev[2][PIPE ? NT : 1];
+    int pn = -1, py0 = 0, px0 = 0;
+
+    int p = blockIdx.x;
+    fetch(p);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (; p < patches; p += gridDim.x) {
         fetch(p + gridDim.x);                               // lands during the MFMAs below (nothing past the end)
         int n, y0, x0;
         decode(p, n, y0, x0);
-        const float *tl = tile[BUF];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
+        const float *tl = tile[buf];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int toff = (t / 3) * RS + (t % 3) * CS;   // halo origin is (y0-1, x0-1): tap (dy,dx) = (t/3-1, t%3-1)
@@ -200,64 +184,38 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 wv = wreg[nt][t][g];
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const bool first = t == 0 && g == 0;
-                    cur[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wv.x, first ? zero : cur[0][nt], 0, 0, 0);
-                    cur[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wv.x, first ? zero : cur[1][nt], 0, 0, 0);
-                    cur[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wv.y, cur[0][nt], 0, 0, 0);
-                    cur[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wv.y, cur[1][nt], 0, 0, 0);
-                    cur[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wv.z, cur[0][nt], 0, 0, 0);
-                    cur[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wv.z, cur[1][nt], 0, 0, 0);
-                    cur[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wv.w, cur[0][nt], 0, 0, 0);
-                    cur[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wv.w, cur[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wv.x, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wv.x, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wv.y, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wv.y, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wv.z, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wv.z, acc[1][nt], 0, 0, 0);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wv.w, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wv.w, acc[1][nt], 0, 0, 0);
                 }
             }
             if constexpr (PIPE) {
-                if (t < 8) epi_piece(t, prv, pod);
+                if (t < 8) epi_piece(t, prev, pn, py0, px0);
             }
         }
-        store(BUF ^ 1);                                     // that buffer was last read before the previous barrier
+        store(buf ^ 1);                                     // that buffer was last read before the previous barrier
         if constexpr (!PIPE) {
-            const OutDesc od = out_desc(n, y0, x0);
 #pragma unroll
-            for (int idx = 0; idx < 8; ++idx) epi_piece(idx, cur, od);
+            for (int idx = 0; idx < 8; ++idx) epi_piece(idx, acc, n, y0, x0);
         }
         __syncthreads();
-        if constexpr (PIPE) pod = out_desc(n, y0, x0);
-        have_prev = true;
-    };
-    f32x16 accA[2][NT], accB[2][NT];
+        buf ^= 1;
+        if constexpr (PIPE) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[u][nt][r] = accB[u][nt][r] = 0.f;
-
-    int p = blockIdx.x;
-    fetch(p);
-    store(0);
-    __syncthreads();
-    bool last_is_a = false;
-    while (p < patches) {
-        step(std::integral_constant<int, 0>{}, accA, accB, p);
-        p += gridDim.x;
-        last_is_a = true;
-        if (p >= patches) break;
-        step(std::integral_constant<int, 1>{}, accB, accA, p);
-        p += gridDim.x;
-        last_is_a = false;
+                for (int nt = 0; nt < NT; ++nt) prev[u][nt] = acc[u][nt];
+            pn = n; py0 = y0; px0 = x0;
+        }
     }
     if constexpr (PIPE) {
-        if (have_prev) {
-            if (last_is_a) {
 #pragma unroll
-                for (int idx = 0; idx < 8; ++idx) epi_piece(idx, accA, pod);
-            } else {
-#pragma unroll
-                for (int idx = 0; idx < 8; ++idx) epi_piece(idx, accB, pod);
-            }
-        }
+        for (int idx = 0; idx < 8; ++idx) epi_piece(idx, prev, pn, py0, px0);
     }
 }
 
