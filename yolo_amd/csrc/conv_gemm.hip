@@ -49,8 +49,11 @@ struct ConvArgs {
     float alpha;
 };
 
+// LDS bytes up to which a tile configuration takes three stages instead of two.  Measured (batch 64, warm clocks): the
+// third stage buys nothing (the fetch is not latency-exposed) and costs a resident workgroup on the small tiles
+// (1-2 % slower), so the ring is two stages deep unless a build overrides this.
 #ifndef TY1_NS3_LIMIT
-#define TY1_NS3_LIMIT (80 * 1024)
+#define TY1_NS3_LIMIT 0
 #endif
 #ifdef TY1_DEV_STAMPS
 #define TY1_DBG(bit) (a.dbg & (bit))
@@ -166,8 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     constexpr unsigned kOOB = 0xFFFFFFFFu;
     static_assert(NKB == 2 || NKB == 4, "BK is 16 or 32");
 
-    // NS stages: the fetch cursor runs NS-1 chunks ahead of the MFMAs.  Three where that keeps two workgroups on a CU
-    // (a chunk of a small tile is too short to cover an L2 miss), else two.
+    // NS stages: the fetch cursor runs NS-1 chunks ahead of the MFMAs (see TY1_NS3_LIMIT above).
     constexpr int NS = 3 * STAGE <= TY1_NS3_LIMIT ? 3 : 2;
     constexpr int PW = TA + TB;                 // DMA instructions per wave and chunk
     __shared__ __attribute__((aligned(16))) char lds[NS * STAGE];
