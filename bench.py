@@ -101,9 +101,7 @@ def main():
     def step():
         boxes, score, cls, keep = model.detect(x)
         if world > 1:                                  # detection gather: fixed-size records, one collective
-            rec[..., :4] = boxes
-            rec[..., 4] = score
-            rec[..., 5] = torch.where(keep.bool(), cls, -1)
+            ops.pack_detections(boxes, score, cls, keep, out=rec)
             dist.all_gather_into_tensor(gathered, rec)
         return keep
 

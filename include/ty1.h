@@ -142,6 +142,15 @@ int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, 
                    double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream);
 
 /*
+ * Wire format after the path: fixed-size records for the multi-GPU detection gather.
+ * The reference has no counterpart beyond drawing the kept boxes (/root/reference/tiny_yolov1.py:142-160);
+ * the record keeps exactly what that loop reads: corners, confidence, class.
+ *   rec (slots, 6) f64 = x0, y0, x1, y1, score, class (-1.0 where keep == 0); slots = N*S*S*B
+ */
+int ty1_pack_detections(const double *boxes, const float *score, const int32_t *cls, const uint8_t *keep,
+                        double *rec, long long slots, ty1_stream_t stream);
+
+/*
  * NumPy twins used by the reference's inference script (geometry in float64):
  *   YOLO_head: feats (N,S,S,B,4) f32 -> xy (N,S,S,B,2) f64, wh (N,S,S,B,2) f32
  *   iou:       n box pairs, mins/maxes (n,2) f64 -> (n) f64

@@ -196,6 +196,19 @@ def test_detection_records_roundtrip_on_device():
     boxes, score, cls, keep = parallel.unpack_detections(parallel.gather_detections(rec))
     assert torch.equal(boxes, det[0]) and torch.equal(keep, det[3]) and torch.equal(score, det[1])
     assert torch.equal(cls[keep.bool()], det[2][keep.bool()])
+    # the HIP packer (device tensors) writes the same records as the host formulation (what the gloo tests pack)
+    host = parallel.pack_detections(*(t.cpu() for t in det))
+    assert rec.is_cuda and torch.equal(rec.cpu(), host)
+    # ragged sizes and a caller-provided output
+    rng = np.random.default_rng(5)
+    for n, slots in [(1, 98), (3, 49), (7, 196)]:
+        b = torch.from_numpy(rng.random((n, slots, 4))).to(DEV)
+        sc = torch.from_numpy(rng.random((n, slots)).astype(np.float32)).to(DEV)
+        cl = torch.from_numpy(rng.integers(0, 20, (n, slots)).astype(np.int32)).to(DEV)
+        kp = torch.from_numpy((rng.random((n, slots)) < 0.3).astype(np.uint8)).to(DEV)
+        out = torch.full((n, slots, 6), float('nan'), dtype=torch.float64, device=DEV)
+        assert ops.pack_detections(b, sc, cl, kp, out=out) is out
+        assert torch.equal(out.cpu(), parallel.pack_detections(b.cpu(), sc.cpu(), cl.cpu(), kp.cpu()))
 
 
 # ------------------------------------------------------------------------------- preprocessing on the GPU (8f row 2)

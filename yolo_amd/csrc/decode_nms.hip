@@ -280,6 +280,20 @@ extern "C" int ty1_iou_f64(const double *pred_mins, const double *pred_maxes, co
     return ty1::check_launch("ty1_iou_f64");
 }
 
+// Fixed-size detection records for the multi-GPU gather: rec[i] = (x0, y0, x1, y1, score, class or -1 if the slot is
+// not kept), all float64 (box corners stay bit-exact).  One thread per slot, one 48-byte record each.
+__global__ __launch_bounds__(256) void pack_detections_kernel(const double *__restrict__ boxes, const float *__restrict__ score,
+                                                               const int32_t *__restrict__ cls, const uint8_t *__restrict__ keep,
+                                                               double *__restrict__ rec, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double2 lo = *reinterpret_cast<const double2 *>(boxes + 4 * i), hi = *reinterpret_cast<const double2 *>(boxes + 4 * i + 2);
+    double2 *o = reinterpret_cast<double2 *>(rec + 6 * i);
+    o[0] = lo;
+    o[1] = hi;
+    o[2] = make_double2((double)score[i], keep[i] ? (double)cls[i] : -1.0);
+}
+
 extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, double iou_thr,
                               double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream) {
     TY1_REQUIRE(N >= 0 && S > 0 && C > 0 && img_size > 0, "ty1_decode_nms: bad dimensions N=%d S=%d C=%d", N, S, C);
@@ -304,4 +318,16 @@ extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int
         default: decode_nms_kernel<4><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
     }
     return ty1::check_launch("ty1_decode_nms");
+}
+
+extern "C" int ty1_pack_detections(const double *boxes, const float *score, const int32_t *cls, const uint8_t *keep,
+                                   double *rec, long long slots, ty1_stream_t stream) {
+    TY1_REQUIRE(slots >= 0, "ty1_pack_detections: bad slot count");
+    if (slots == 0) return 0;
+    TY1_REQUIRE(boxes && score && cls && keep && rec, "ty1_pack_detections: null pointer");
+    TY1_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)rec & 15) == 0, "ty1_pack_detections: boxes and rec must be 16-byte aligned");
+    TY1_REQUIRE(slots < (1ll << 31) * 256, "ty1_pack_detections: too many slots");
+    ty1::ProfScope prof("pack_detections", (hipStream_t)stream, 0.0, 89.0 * (double)slots);
+    pack_detections_kernel<<<(unsigned)((slots + 255) / 256), 256, 0, (hipStream_t)stream>>>(boxes, score, cls, keep, rec, slots);
+    return ty1::check_launch("ty1_pack_detections");
 }

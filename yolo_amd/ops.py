@@ -198,6 +198,17 @@ def decode_nms(pred, B=2, C=20, img_size=448, iou_thr=0.2, out=None):
     return boxes, score, cls, keep
 
 
+def pack_detections(boxes, score, cls, keep, out=None):
+    """-> (N, slots, 6) f64 records x0,y0,x1,y1,score,class (-1 where not kept): the unit of the detection gather."""
+    _chk(boxes, torch.float64, 'boxes'); _chk(score, torch.float32, 'score'); _chk(cls, torch.int32, 'cls'); _chk(keep, torch.uint8, 'keep')
+    N, slots = score.shape
+    if out is None:
+        out = torch.empty((N, slots, 6), dtype=torch.float64, device=boxes.device)
+    _lib.call('ty1_pack_detections', boxes.data_ptr(), score.data_ptr(), cls.data_ptr(), keep.data_ptr(), out.data_ptr(),
+              N * slots, _lib.current_stream())
+    return out
+
+
 def yolo_head(feats, img_size=448):
     _chk(feats, torch.float32, 'feats')
     if feats.dim() != 5 or feats.shape[-1] != 4 or feats.shape[1] != feats.shape[2]:

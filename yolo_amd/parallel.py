@@ -33,7 +33,11 @@ RECORD_WIDTH = 6        # x0, y0, x1, y1, score, class (-1 where the slot is not
 
 
 def pack_detections(boxes, score, cls, keep):
-    """-> (n, slots, 6) float64 fixed-size records (float64 keeps the box corners bit-exact)."""
+    """-> (n, slots, 6) float64 fixed-size records (float64 keeps the box corners bit-exact).
+    Device tensors go through one HIP kernel (ty1_pack_detections); host tensors (gloo tests) through torch."""
+    if boxes.is_cuda:
+        from . import ops
+        return ops.pack_detections(boxes, score, cls, keep)
     rec = torch.empty(boxes.shape[:2] + (RECORD_WIDTH,), dtype=torch.float64, device=boxes.device)
     rec[..., :4] = boxes
     rec[..., 4] = score
