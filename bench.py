@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample: seconds of host work to time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-gather', action='store_true', help='developer check: run the N>1 code path (process group, detection gather) on one rank')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -79,9 +80,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_gather
+    if multi:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     from yolo_amd import ops, params as P
     from yolo_amd.engine import DeviceModel
@@ -93,21 +97,21 @@ def main():
     x = x_cpu.to(dev)
     ws = model.workspace(N)
     gathered = None
-    if world > 1:
+    if multi:
         slots = 98
         rec = torch.empty((N, slots, 6), dtype=torch.float64, device=dev)          # box(4) score cls*keep
         gathered = torch.empty((world * N, slots, 6), dtype=torch.float64, device=dev)
 
     def step():
         boxes, score, cls, keep = model.detect(x)
-        if world > 1:                                  # detection gather: fixed-size records, one collective
+        if multi:                                      # detection gather: fixed-size records, one collective
             ops.pack_detections(boxes, score, cls, keep, out=rec)
             dist.all_gather_into_tensor(gathered, rec)
         return keep
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
@@ -136,7 +140,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         live = kt.table()
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +204,7 @@ def main():
                                    'torch.rand images resident in HBM',
                        'global_batch': world * N, 'per_gpu_batch': N,
                        'sharding': 'batch split across ranks, no data-path collective'
-                                   + ('; all-gather of fixed-size detection records inside the step' if world > 1 else ''),
+                                   + ('; all-gather of fixed-size detection records inside the step' if multi else ''),
                        'kept_boxes_per_image': round(kept_per_image, 2)},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'rocprof_symbol': ROCPROF_SYMBOL.get(dom_name),
                          'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -221,7 +225,7 @@ def main():
             cb['value'] = round(cb['value'], 2)
             out['cpu_baseline'] = cb
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
