@@ -21,6 +21,8 @@
 // Two workgroups (2 x 29.4 KB of LDS each) share a CU.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -549,10 +551,14 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         const long long o_left = (y_total - o_org) * OSZ;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             static_cast<char *>(y) + o_org * OSZ, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
-        auto put = [&](float v, unsigned off) {
-            if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
+        auto put = [&](float v, unsigned off, int soff) {
+            if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, soff, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, soff, 0);
         };
+        // a patch that lies wholly inside the image needs no per-store test: the tile part of the offset is a scalar
+        // (the store's scalar offset), so a store costs no vector instruction besides itself - every one of those
+        // costs the matrix pipe ~8 cycles, and this layer has one store per 7 MFMAs
+        const bool full = y0 + C3_TH <= H && x0 + C3_TW <= W;
         // output rows / columns of the image left from this lane's first element (a tile is valid below them)
         const int rows_left = Ho - oy0 - (POOL ? 2 : 4) * wave;
         const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * kq;
@@ -597,7 +603,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                     }
             }
         };
-        auto finish = [&](int t2, const f32x4 (&acc)[2][NT]) {
+        auto finish = [&](auto full_c, int t2, const f32x4 (&acc)[2][NT]) {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = t2 + u, pr = t >> 3, wc = t & 7;
@@ -610,41 +617,53 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                         // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
                         const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
                         const float v = m > 0.f ? m : m * alpha;
-                        const bool ok = pr < rows_left && 4 * wc < cols_left;
-                        const unsigned off = ok ? lane_off + (unsigned)pr * row_b + (unsigned)(4 * wc) * px_b + 16u * OSZ * j : kOOB;
-                        put(v, off);
+                        const int tile_off = pr * (int)row_b + 4 * wc * (int)px_b + 16 * (int)OSZ * j;
+                        if constexpr (FULL) {
+                            put(v, lane_off, tile_off);
+                        } else {
+                            const bool ok = pr < rows_left && 4 * wc < cols_left;
+                            put(v, ok ? lane_off + (unsigned)tile_off : kOOB, 0);
+                        }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
                             const int dy = 2 * pr + (r >> 1), dx = 8 * wc + (r & 1);
-                            const bool ok = dy < rows_left && dx < cols_left;
-                            const unsigned off = ok ? lane_off + (unsigned)dy * row_b + (unsigned)dx * px_b + 16u * OSZ * j : kOOB;
-                            put(v, off);
+                            const int tile_off = dy * (int)row_b + dx * (int)px_b + 16 * (int)OSZ * j;
+                            if constexpr (FULL) {
+                                put(v, lane_off, tile_off);
+                            } else {
+                                const bool ok = dy < rows_left && dx < cols_left;
+                                put(v, ok ? lane_off + (unsigned)tile_off : kOOB, 0);
+                            }
                         }
                     }
                 }
             }
         };
-        f32x4 accA[2][NT], accB[2][NT];
-        float avA[KS][2], avB[KS][2];
-        load_a(0, avA);
-        load_a(2, avB);
-        compute(avA, accA);
-        // the fences pin "reads of the step after next | MFMAs of the next step + epilogue of this one" as stages
+        auto patch_body = [&](auto full_c) {
+            f32x4 accA[2][NT], accB[2][NT];
+            float avA[KS][2], avB[KS][2];
+            load_a(0, avA);
+            load_a(2, avB);
+            compute(avA, accA);
+            // the fences pin "reads of the step after next | MFMAs of the next step + epilogue of this one" as stages
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (it < 3) load_a(4 * it + 4, avA);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(avB, accB);
-            finish(4 * it, accA);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it < 3) load_a(4 * it + 6, avB);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it < 3) compute(avA, accA);
-            finish(4 * it + 2, accB);
-        }
+            for (int it = 0; it < 4; ++it) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (it < 3) load_a(4 * it + 4, avA);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(avB, accB);
+                finish(full_c, 4 * it, accA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it < 3) load_a(4 * it + 6, avB);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it < 3) compute(avA, accA);
+                finish(full_c, 4 * it + 2, accB);
+            }
+        };
+        if (full) patch_body(std::true_type{});
+        else patch_body(std::false_type{});
         C3_STAMP(ts2);
         store(buf ^ 1);                                      // that buffer was last read before the previous barrier
         C3_STAMP(ts3);
