@@ -183,6 +183,35 @@ def test_model_end_to_end_vs_oracle(N, C, bn):
     assert_detections_equal(got, oracle.decode_nms(y, 2, C, 448))
 
 
+def test_model_full_batch_properties():
+    """BASELINE configs[1] at its full size (batch 64, fp32), where the oracle would take minutes: size-independent
+    properties.  The batch-64 launch shapes are the ones bench.py times (49 * 2^k tiles, K-split tails, fix-up), which
+    the small cases above do not reach."""
+    N = 64
+    prm = P.make_random_params(seed=1, C=20, dense_init='spread', bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(0))
+    model = DeviceModel(prm, C=20, device=DEV)
+    xd = x.to(DEV)
+    y = model.predict(xd).clone()
+    # determinism: fixed-order reductions, a second run gives the same bits
+    assert torch.equal(model.predict(xd), y)
+    # three images of the batch against the oracle (fp32 bar of north_star: 1e-3 relative)
+    pick = [0, 31, 63]
+    y_ref = model_ref.model_ref(x[pick].numpy(), prm, 7, 2, 20)
+    np.testing.assert_allclose(y[pick].cpu().numpy(), y_ref, rtol=1e-3, atol=1e-4)
+    # batch independence: an image's result does not depend on its neighbours or its position (the K-split tail
+    # changes the f32 summation order of some tiles with the batch size, hence a tolerance instead of bits)
+    for i in (0, 17, 63):
+        yi = model.predict(xd[i:i + 1].contiguous())[0]
+        torch.testing.assert_close(yi, y[i], rtol=1e-3, atol=1e-4)     # measured: 3e-5 absolute
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1))
+    yp = model.predict(xd[perm.to(DEV)].contiguous())
+    torch.testing.assert_close(yp, y[perm.to(DEV)], rtol=1e-3, atol=1e-4)
+    # detections at full batch: bit-exact against the oracle fed the GPU's own scores
+    y_np = y.cpu().numpy()
+    assert_detections_equal(model.detect(xd), oracle.decode_nms(y_np, 2, 20, 448))
+
+
 # ------------------------------------------------------------------------------- loss
 @pytest.mark.parametrize('name,C', [('loss_c20.npz', 20), ('loss_c1.npz', 1)])
 def test_yolo_loss_vs_reference_goldens(name, C):
