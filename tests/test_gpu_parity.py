@@ -126,7 +126,11 @@ LAYERS = [(2, 448, 3, 16, True), (2, 224, 16, 32, True), (2, 112, 32, 64, True),
           (3, 28, 128, 256, True), (5, 14, 256, 512, True), (5, 7, 512, 1024, False), (5, 7, 1024, 256, False),
           # shapes outside the model: odd tiles / tails / no-pool variants of the early layers
           (1, 40, 3, 16, False), (1, 36, 3, 32, True), (1, 20, 16, 32, False), (2, 10, 32, 64, True),
-          (1, 6, 64, 128, False), (70, 7, 64, 64, False)]
+          (1, 6, 64, 128, False), (70, 7, 64, 64, False),
+          # the other tile configurations of the dispatcher: 256x32 tiles (one B row group: guarded DMA pieces), 64-byte
+          # K chunks with an odd chunk count (Cin = 48), a Cout that is not a multiple of the tile (192 = 3 x 64, 96)
+          (2, 12, 32, 32, True), (3, 9, 32, 32, False), (1, 9, 48, 96, False), (2, 10, 48, 64, True), (3, 8, 96, 192, True),
+          (1, 11, 160, 96, False)]
 
 
 # whole tiles + K-split tail (294 tiles on 256 CUs), and a deep-K 7x7 layer that is all tail
