@@ -60,7 +60,8 @@ CASES = [(2, 448, 3, 16, True, False), (2, 224, 16, 32, True, False), (2, 112, 3
          (5, 7, 512, 1024, False, False), (5, 7, 1024, 256, False, True),
          (1, 36, 3, 32, True, False), (1, 40, 3, 16, False, False), (1, 20, 16, 32, False, False), (1, 22, 16, 64, True, False),
          (2, 10, 32, 64, True, False), (1, 6, 64, 128, False, True), (70, 7, 64, 64, False, False),
-         (24, 28, 128, 256, True, False), (12, 7, 1024, 256, False, True)]
+         (24, 28, 128, 256, True, False), (12, 7, 1024, 256, False, True),
+         (2, 10, 96, 192, True, False), (1, 9, 160, 64, False, True)]      # odd chunk counts, Cout = 3 x 64
 
 
 @pytest.mark.parametrize('use_ws', [False, True])
