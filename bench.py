@@ -124,12 +124,18 @@ def main():
     # continue until the GPU has been busy for `--settle-ms` (default 200 ms) before anything is measured; the count is
     # reported as `settle_steps`.  The timed region below is still exactly K steps.
     settle_steps = 0
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_steps < 2000:
-        for _ in range(10):
+    if multi:
+        # every rank must issue the same number of collectives: a fixed count (~1.6 ms per step), not a local clock
+        settle_steps = int(args.settle_ms / 1.6)
+        for _ in range(settle_steps):
             step()
-        torch.cuda.synchronize(dev)
-        settle_steps += 10
+    else:
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_steps < 2000:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+            settle_steps += 10
     sync_all()
     # ---- survey pass (untimed): every library launch brackets itself with HIP events on its own stream; this gives
     #      the per-kernel table and names the dominant kernel.  Bracketing EVERY launch costs ~5 % of a step, so the
