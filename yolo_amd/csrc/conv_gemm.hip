@@ -999,6 +999,8 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     }
 
     TY1_REQUIRE(Cin % 16 == 0, "ty1_conv3x3: Cin=%d must be 3 or a multiple of 16", Cin);
+    // 32-bit buffer offsets: a tile's rows span at most two images plus one halo row
+    TY1_REQUIRE((2ll * H * W + 2ll * (W + 1)) * Cin * 4 < (1ll << 31), "ty1_conv3x3: one image (%dx%dx%d) is too large for 32-bit offsets", H, W, Cin);
     if (!ws_need)
         TY1_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)ws & 15) == 0,
                     "ty1_conv3x3: x, w and workspace must be 16-byte aligned");
@@ -1081,6 +1083,7 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
         return ty1::conv3x3_c16_direct_bf16(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, s);
     }
     TY1_REQUIRE(Cin % 32 == 0, "ty1_conv3x3_bf16: Cin=%d must be 3, 16 or a multiple of 32", Cin);
+    TY1_REQUIRE((2ll * H * W + 2ll * (W + 1)) * Cin * 2 < (1ll << 31), "ty1_conv3x3_bf16: one image (%dx%dx%d) is too large for 32-bit offsets", H, W, Cin);
     ConvArgs a{};
     a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w); a.scale = scale; a.shift = shift;
     a.y = static_cast<float *>(y);
