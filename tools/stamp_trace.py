@@ -31,7 +31,7 @@ for _ in range(args.launches):                      # back to back: the last lau
 torch.cuda.synchronize()
 _lib.call('ty1_debug_stamp_buffer', None, 0)
 ball = buf.cpu().numpy()
-b = ball[:cap // 2]
+b = ball[:4096]                      # block rows; rows 4096... hold the per-item clock trace of blocks 0-7
 b = b[b[:, 0] != 0]
 nb = len(b)
 t0 = b[:, 0].min()
@@ -52,7 +52,7 @@ if args.persist:
     print(f'per item (shader cycles): loop {np.mean(b[:, 1] / ni):.0f}  epilogue {np.mean(b[:, 2] / ni):.0f}  rows {np.mean(b[:, 6] / ni):.0f}'
           f'   block time {np.mean(end - st):.1f} us -> {np.mean((end - st) / ni):.2f} us per item')
     print(f'shader clock while a block runs (stamped cycles / block time): {np.mean((b[:, 1] + b[:, 2] + b[:, 6]) / np.maximum(end - st, 1e-9)) / 1e3:.3f} GHz')
-    tr = ball[1024:1024 + 64]
+    tr = ball[4096:4096 + 64]
     tr = tr[tr[:, 1] != 0]
     if len(tr) > 2:
         ck = np.diff(tr[:, 0]) / np.diff(tr[:, 1]) * 0.1
@@ -61,7 +61,7 @@ if args.persist:
     print('end-time histogram:', np.histogram(end, bins=8)[0].tolist(), f'first {end.min():.1f} last {end.max():.1f}')
     hw = b[:, 4]; xcc = b[:, 5] & 0xF
     cuid = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xF)
-    ids = np.nonzero(ball[:cap // 2, 0] != 0)[0]
+    ids = np.nonzero(ball[:4096, 0] != 0)[0]
     groups = {}
     for bi, c in zip(ids, cuid):
         groups.setdefault(int(c), []).append(int(bi))
@@ -69,5 +69,13 @@ if args.persist:
     print('CUs', len(groups), 'blocks per CU', np.bincount([len(g) for g in groups.values()]).tolist(),
           'index distance of CU partners:', dict(zip(*[x.tolist() for x in np.unique(diffs, return_counts=True)])))
     print('xcc of blocks 0..15:', xcc[:16].tolist())
+    print('mean end time per XCD (us):', [round(float(end[xcc == k].mean()), 1) for k in range(8)])
+    cu_end = {c: max(end[ids.tolist().index(bi)] for bi in g) for c, g in groups.items()}
+    by_n = {}
+    for c, g in groups.items():
+        by_n.setdefault(len(g), []).append(cu_end[c])
+    print('CU end time by resident blocks:', {k: (len(v), round(float(np.mean(v)), 1), round(float(np.min(v)), 1), round(float(np.max(v)), 1)) for k, v in sorted(by_n.items())})
+    cyc = (b[:, 1] + b[:, 2] + b[:, 6])
+    print('stamped cycles per block: mean %.0f min %.0f max %.0f; block time mean %.1f min %.1f max %.1f us' % (cyc.mean(), cyc.min(), cyc.max(), (end - st).mean(), (end - st).min(), (end - st).max()))
     sys.exit(0)
 sys.exit('pass --persist (conv_persist_kernel layers) or --direct (first layer, TY1_DEV_STAMPS build)')

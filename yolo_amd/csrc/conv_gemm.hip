@@ -629,9 +629,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         if (a.stamp) {
             const long long t3 = __builtin_amdgcn_s_memtime();
             t_loop += t1 - t0; t_epi += t2 - t1; t_rows += t3 - t2; ++n_items;
-            if (tid == 0 && blockIdx.x < 8 && n_items < 64) {     // per-item clock trace of the first blocks (rows 1024...)
-                a.stamp[(1024 + blockIdx.x * 64 + n_items) * 8 + 0] = t3;
-                a.stamp[(1024 + blockIdx.x * 64 + n_items) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0 && blockIdx.x < 8 && n_items < 64) {     // per-item clock trace of the first blocks (rows 4096...)
+                a.stamp[(4096 + blockIdx.x * 64 + n_items) * 8 + 0] = t3;
+                a.stamp[(4096 + blockIdx.x * 64 + n_items) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
             }
         }
     }
@@ -881,13 +881,17 @@ TailPlan plan_tail(int T, int C, int slots) {
     TailPlan p{T, 0, 1};
     static const char *off = getenv("TY1_NO_TAIL_SPLIT");
     if (off || T % slots == 0 || C < 2) return p;
-    const double ovh = 3.0, fix = 4.0;
+    // (measured with per-CU end-time stamps, 7x7x512->1024 at batch 64: 96 pieces left 160 CUs idle for the last 5 % of the
+    //  kernel; the piece count that gives every CU the same share wins even though it is the largest split)
+    const double ovh = 3.0, fix = 4.0, fix_per_split = 0.1;
     double best = std::ceil((double)T / slots) * (C + ovh);
     const int rem = T % slots, whole = T - rem;
+    static const char *hyst = getenv("TY1_TAIL_HYST");        // developer override: required gain per step (default 0.5 %)
+    const double need = hyst ? atof(hyst) : 0.995;
     for (int s = 2; s <= 32 && C / s >= 3; ++s) {        // a piece keeps >= 3 chunks (fetch cursor of the persistent kernel)
         const int per = (C + s - 1) / s;
-        const double t = (double)whole / slots * (C + ovh) + std::ceil((double)rem * s / slots) * (per + ovh) + fix;
-        if (t < 0.96 * best) {
+        const double t = (double)whole / slots * (C + ovh) + std::ceil((double)rem * s / slots) * (per + ovh) + fix + fix_per_split * s;
+        if (t < need * best) {
             best = t;
             p = TailPlan{whole, rem, s};
         }
