@@ -73,7 +73,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent conv kernel.  The grid is two workgroups per CU; workgroup b walks the work items
+// Persistent conv kernel.  The grid is as many workgroups as stay resident (two to four per CU); workgroup b walks the work items
 // slot(b), slot(b) + G, slot(b) + 2G ... (item = output tile x K-split piece) as ONE continuous stream of
 // K chunks: the fetch cursor runs NS-1 chunks ahead of the MFMAs and simply crosses into the next item,
 // so a new tile starts with its operands already in LDS - no per-tile prologue (address arithmetic +
@@ -82,13 +82,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // multiply-shift division.
 // Software pipeline of one wave (the matrix pipe should never wait for this wave's own memory work).  Per chunk, right
 // after the barrier that published it:
-//   1. read the fragments of its first k-block                (latency hidden by 2.)
-//   2. store the NEXT chunk (fetched a whole chunk ago) to the other LDS buffer and immediately re-issue the fetch of
-//      the chunk after that into the same registers; the 32 KB of LDS stores per block (the VGPR->LDS path moves
-//      ~79 B/clk per CU) drain behind the MFMAs that follow
+//   1. read the fragments of its first k-block
+//   2. issue the LDS-DMA fetch of the NEXT chunk into the stage that was read last (between the first MFMA groups;
+//      it costs the matrix pipe nothing and has the whole chunk to land)
 //   3. the second half of the previous chunk's last k-block (8 MFMAs kept back across the barrier)
 //   4. k-blocks 0..NKB-1 with the fragments of k-block kb+1 read while k-block kb multiplies
-//   5. barrier with half of the last k-block still to issue; 6. cursor step (the only branch of the body).
+//   5. counted vmcnt wait + raw barrier with half of the last k-block still to issue; 6. cursor step (the only branch).
 // The body is the same for every chunk (no peeling: peeled copies make the register allocator shuffle the 64
 // accumulator registers around the loop); an item's first pass multiplies a zero fragment in step 3.
 // ------------------------------------------------------------------------------------------------
@@ -103,7 +102,7 @@ FastDiv make_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.M) + n) >> f.l; }
 
 // Element type of the GEMM operands (activations and weights).  A K chunk is always BK*4 bytes of a row (8 or 4
-// 16-byte pieces), so fetch, LDS layout and swizzle do not depend on it; only the fragment -> MFMA step does:
+// 16-byte pieces), so fetch and LDS layout do not depend on it; only the fragment -> MFMA step does:
 // a 16-byte LDS read holds 4 floats = the operands of four v_mfma_f32_32x32x2_f32 (k = 2 each, lane half = k
 // parity), or 8 bf16 = the operand of ONE v_mfma_f32_32x32x16_bf16 (lane half = k 8h..8h+7).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
