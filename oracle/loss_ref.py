@@ -126,7 +126,11 @@ def yolo_loss_closed_form(y_true, y_pred, C=20, B=2, img_size=448):
         gbox[..., k, 0] = -10 * MR[..., k] * dx / (S * S)
         gbox[..., k, 1] = -10 * MR[..., k] * dy / (S * S)
         with np.errstate(all='ignore'):
-            gbox[..., k, 2] = np.where(MR[..., k] > 0, 5 * MR[..., k] * (1 - np.sqrt(l[..., 2] / box[..., k, 2])) / img_size, 0)
-            gbox[..., k, 3] = np.where(MR[..., k] > 0, 5 * MR[..., k] * (1 - np.sqrt(l[..., 3] / box[..., k, 3])) / img_size, 0)
+            for j in (2, 3):
+                # autodiff through K.sqrt = sqrt(clip(., 0)): no gradient for w < 0; at w == 0 the chain rule gives
+                # 0 * inf = NaN even for a box that is not responsible (golden cells [2,3,3] and [3,4,2])
+                b_, l_ = box[..., k, j], np.maximum(l[..., j], 0)
+                g_ = np.where(MR[..., k] > 0, 5 * MR[..., k] * (1 - np.sqrt(l_ / b_)) / img_size, np.where(b_ == 0, np.nan, 0))
+                gbox[..., k, j] = np.where(b_ < 0, 0, g_)
     grad[..., C + B:] = gbox.reshape(N, S, S, 4 * B)
     return loss, grad

@@ -16,6 +16,9 @@ Outputs (small .npz files next to this script):
   loss_c20.npz   (y_true, y_pred) -> loss, dL/dy_pred, yolo_head, iou of yolo/yolo.py
                  (/root/reference/yolo/yolo.py:6-107)
   loss_c1.npz    same for faces.trainFace.yolo_loss (/root/reference/faces/trainFace.py:66-126)
+  head_c20.npz   Dense output z (n,1470) -> ReshapeYOLO((7,7,30)).call(z)
+                 (/root/reference/models/model_tiny_yolov1.py:14-34)
+  head_c1.npz    z (n,539) -> ReshapeYOLO((7,7,11)).call(z)  (/root/reference/faces/trainFace.py:30-63)
 
 Usage: python tests/golden/make_golden.py
 """
@@ -116,6 +119,10 @@ def _k_shim():
                                                    else torch.sum(x, dim=axis, keepdim=keepdims))
     # Keras backend sqrt clips its argument to [0, inf) before tf.sqrt.
     K.sqrt = lambda x: torch.sqrt(torch.clamp(x, min=0.0))
+    # ReshapeYOLO.call (models/model_tiny_yolov1.py:14-34) needs three more; Keras defaults: axis=-1
+    K.softmax = lambda x, axis=-1: torch.softmax(_t(x), dim=axis)
+    K.sigmoid = lambda x: torch.sigmoid(_t(x))
+    K.concatenate = lambda xs, axis=-1: torch.cat([_t(v) for v in xs], dim=axis)
     return K
 
 
@@ -249,6 +256,21 @@ def make_loss_inputs(C, rng, N):
     y_true[1, 0, 0, C:C + 4] = [0.5, 0.5, 0.01, 0.01]
     y_true[1, 0, 0, C + 4] = 1
     y_pred[1, 0, 0, C + 2:] = [0.99, 0.99, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01]
+    # a labelled cell with a zero-area label AND a zero-area predicted box 0: iou_0 = 0/0 = NaN, K.max propagates it,
+    # `>=` is False for both boxes -> neither is responsible (yolo/yolo.py:79-82); the sqrt of the zero width has an
+    # infinite derivative, so autodiff gives 0 * inf = NaN for dL/dw, dL/dh of that box
+    y_true[2, 3, 3, :] = 0
+    y_true[2, 3, 3, 0] = 1
+    y_true[2, 3, 3, C:C + 4] = [0.5, 0.5, 0.0, 0.0]
+    y_true[2, 3, 3, C + 4] = 1
+    y_pred[2, 3, 3, C + 2:C + 6] = [0.25, 0.75, 0.0, 0.0]
+    # a labelled cell (ordinary label) whose predicted box 0 has zero width: iou_0 = 0, box 1 responsible
+    y_true[3, 4, 2, :] = 0
+    y_true[3, 4, 2, 0] = 1
+    y_true[3, 4, 2, C:C + 4] = [0.5, 0.5, 0.3, 0.4]
+    y_true[3, 4, 2, C + 4] = 1
+    y_pred[3, 4, 2, C + 2:C + 6] = [0.5, 0.5, 0.0, 0.2]
+    y_pred[3, 4, 2, C + 6:C + 10] = [0.4, 0.6, 0.25, 0.35]
     return y_true, y_pred.astype(np.float32)
 
 
@@ -380,6 +402,28 @@ def run_loss(module_loss, head_fn, iou_fn, C, rng, N, path, img_size):
     print(f'{os.path.basename(path)}: N={N} loss={loss.item():.6f} |grad|max={yp.grad.abs().max():.4f}')
 
 
+def run_head(layer_cls, target_shape, C, path, seed):
+    """The reference's own ReshapeYOLO.call on seeded Dense outputs (planar logits), incl. saturating extremes."""
+    rng = np.random.default_rng(seed)
+    S, D = target_shape[0], target_shape[2]
+    units = S * S * D
+    z = (3.0 * rng.standard_normal((10, units))).astype(np.float32)
+    z[1] *= 10.0                                   # |z| up to ~100: softmax needs the max-subtraction
+    z[2, ::3] = 30.0
+    z[2, 1::3] = -30.0
+    z[3] = 0.0
+    z[4, :S * S * C] = 88.0 + rng.random(S * S * C).astype(np.float32)      # exp() of these overflows fp32 without it
+    z[5] = -104.0 + rng.random(units).astype(np.float32)                   # sigmoid underflows towards 0
+    z[6] = np.float32(1e-4) * rng.standard_normal(units).astype(np.float32)
+    layer = layer_cls(target_shape)
+    with torch.no_grad():
+        y = layer.call(torch.from_numpy(z))
+    assert tuple(y.shape) == (10,) + tuple(target_shape)
+    assert layer.compute_output_shape((None, units)) == (None,) + tuple(target_shape)
+    np.savez_compressed(path, z=z, y=y.numpy(), C=np.int32(C))
+    print(f'{os.path.basename(path)}: ReshapeYOLO{tuple(target_shape)}.call on {z.shape}')
+
+
 def main():
     cv = install_stubs()
     rng = np.random.default_rng(20260101)
@@ -400,6 +444,11 @@ def main():
     from faces import trainFace
     run_loss(trainFace.yolo_loss, ref_yolo.yolo_head, ref_yolo.iou, 1, rng, 6,
              os.path.join(OUT, 'loss_c1.npz'), 224)
+
+    # head activations: the model files' own layer (own rng: the streams of the fixtures above stay as they were)
+    from models import model_tiny_yolov1 as ref_model
+    run_head(ref_model.ReshapeYOLO, (7, 7, 30), 20, os.path.join(OUT, 'head_c20.npz'), 20260202)
+    run_head(trainFace.ReshapeYOLO, (7, 7, 11), 1, os.path.join(OUT, 'head_c1.npz'), 20260203)
 
 
 if __name__ == '__main__':

@@ -167,6 +167,30 @@ def test_dense_head_vs_oracle(N, C):
     np.testing.assert_allclose(y, y_ref, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize('name,C', [('head_c20.npz', 20), ('head_c1.npz', 1)])
+def test_head_activate_vs_reference_goldens(name, C):
+    """ty1_head_activate_f32 against the output of the reference's own ReshapeYOLO.call (tests/golden/make_golden.py).
+    Bar: 1e-3 relative (north_star); measured error is a few ulp of expf, hence the tighter figures below."""
+    g = load_golden(name)
+    z, want = g['z'], g['y']
+    n, units = z.shape
+    ldz = ops.round_up(units, 4)
+    part = np.zeros((1, n, ldz), np.float32)
+    part[0, :, :units] = z
+    y = ops.head_activate(dev(part), None, 7, 2, C).cpu().numpy()
+    np.testing.assert_allclose(y, want, rtol=1e-5, atol=1e-7)
+    # the same logits delivered as three split-K partials plus a bias
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal(units).astype(np.float32)
+    parts = np.zeros((3, n, ldz), np.float32)
+    parts[0, :, :units] = rng.standard_normal((n, units)).astype(np.float32)
+    parts[1, :, :units] = rng.standard_normal((n, units)).astype(np.float32)
+    parts[2, :, :units] = z - b - parts[0, :, :units] - parts[1, :, :units]
+    y3 = ops.head_activate(dev(parts), dev(b), 7, 2, C).cpu().numpy()
+    moderate = np.abs(z).max(axis=1) < 20            # (re-associating +-100 logits loses more than the bar checks)
+    np.testing.assert_allclose(y3[moderate], want[moderate], rtol=1e-3, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------- whole model
 @pytest.mark.parametrize('N,C,bn', [(2, 20, 'random'), (1, 1, 'identity')])
 def test_model_end_to_end_vs_oracle(N, C, bn):
@@ -225,6 +249,8 @@ def test_yolo_loss_vs_reference_goldens(name, C):
     assert abs(loss.item() - g['loss']) <= 1e-5 * abs(g['loss'])
     np.testing.assert_allclose(per.cpu().numpy(), g['loss_per_image'], rtol=1e-5)
     np.testing.assert_allclose(grad.cpu().numpy(), g['grad'], rtol=1e-4, atol=1e-6)
+    # the two adversarial cells of make_loss_inputs: NaN IoU -> no responsible box; zero-width box -> NaN dL/dw (autodiff)
+    assert np.array_equal(np.isnan(grad.cpu().numpy()), np.isnan(g['grad'])) and np.isnan(g['grad']).sum() == 3
     boxes = dev(g['y_pred'][..., C + 2:]).reshape(-1, 7, 7, 2, 4).contiguous()
     xy, wh = ops.yolo_head(boxes, img)
     assert np.array_equal(xy.cpu().numpy(), g['head_xy']) and np.array_equal(wh.cpu().numpy(), g['head_wh'])

@@ -51,6 +51,24 @@ def test_head_activate_against_numpy_planar_split():
         assert got.shape == (3, S, S, C + 5 * B)
 
 
+@pytest.mark.parametrize('name,C', [('head_c20.npz', 20), ('head_c1.npz', 1)])
+def test_head_activate_matches_reference_goldens(name, C):
+    """PINNED: tests/golden/head_c*.npz hold the output of the reference's own ReshapeYOLO.call
+    (/root/reference/models/model_tiny_yolov1.py:14-34, C=1 twin /root/reference/faces/trainFace.py:38-58) run by
+    tests/golden/make_golden.py on seeded Dense outputs, including saturating logits."""
+    from conftest import load_golden
+    g = load_golden(name)
+    assert int(g['C']) == C
+    got = model_ref.head_activate_ref(g['z'], 7, 2, C)
+    assert got.shape == g['y'].shape == (g['z'].shape[0], 7, 7, C + 10)
+    np.testing.assert_allclose(got, g['y'], rtol=1e-6, atol=1e-30)
+    assert np.isfinite(g['y']).all()                       # the extremes did not overflow the reference's softmax
+    if C > 1:
+        np.testing.assert_allclose(g['y'][..., :C].sum(-1), 1.0, rtol=1e-5)
+    else:
+        assert (g['y'][..., 0] == 1.0).all()               # softmax over one class (SURVEY Q14)
+
+
 def test_flatten_is_hwc_and_dense_is_x_at_w():
     """Flatten of a channels-last (7,7,256) tensor is HWC order; Dense is x @ W + b."""
     rng = np.random.default_rng(9)

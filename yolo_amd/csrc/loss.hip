@@ -11,6 +11,22 @@
 
 namespace {
 
+// K.max (tf.reduce_max; torch.amax in the golden generator's backend mapping): a NaN operand gives NaN
+__device__ __forceinline__ float max_nan(float a, float b) {
+    if (a != a) return a;
+    if (b != b) return b;
+    return a >= b ? a : b;
+}
+
+// d/dw of 5*MR*((sqrt(clip(img*lw, 0)) - sqrt(clip(img*w, 0))) / img)^2 as autodiff delivers it (K.sqrt clips its argument
+// at 0 first): the clip passes no gradient for w < 0; at w == 0 the square root's derivative is infinite, so the chain
+// rule gives 0 * inf = NaN even where the box is not responsible (MR == 0).
+__device__ __forceinline__ float dwh(float MR, float l, float b, float img) {
+    if (b < 0.f) return 0.f;
+    if (MR > 0.f) return 5.f * MR * (1.f - sqrtf(fmaxf(l, 0.f) / b)) / img;
+    return b == 0.f ? __builtin_nanf("") : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -65,8 +81,9 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(const float *__restrict_
             ph[k] = bh[k] * img;
             ious[k] = iou_f32(px[k] - pw[k] / 2, py[k] - ph[k] / 2, px[k] + pw[k] / 2, py[k] + ph[k] / 2, lminx, lminy,
                               lmaxx, lmaxy);
-            // K.max: reduce_max ignores nothing; NaN compares false below either way
-            best = (k == 0) ? ious[k] : fmaxf(best, ious[k]);
+            // K.max :79-80 propagates a NaN IoU (0/0: zero-area label and zero-area box); `>=` below is then False for
+            // every box of the cell and none is responsible
+            best = (k == 0) ? ious[k] : max_nan(best, ious[k]);
         }
         // class loss :89
         float acc = 0.f;
@@ -92,9 +109,8 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(const float *__restrict_
                 float *gb = g + C + B + 4 * k;
                 gb[0] = -10.f * MR * (lx - bx[k]) / (fS * fS);
                 gb[1] = -10.f * MR * (ly - by[k]) / (fS * fS);
-                // d/dw of 5*MR*((sqrt(img*lw) - sqrt(img*w))/img)^2 ; zero where the box is not responsible
-                gb[2] = MR > 0.f ? 5.f * MR * (1.f - sqrtf(lw / bw[k])) / img : 0.f;
-                gb[3] = MR > 0.f ? 5.f * MR * (1.f - sqrtf(lh / bh[k])) / img : 0.f;
+                gb[2] = dwh(MR, lw, bw[k], img);
+                gb[3] = dwh(MR, lh, bh[k], img);
             }
         }
         cell_loss = acc;
