@@ -94,8 +94,9 @@ int ty1_cast_f32_to_bf16(const float *x, void *y, long long n, ty1_stream_t stre
  * -> optional channel swap (cv2.cvtColor BGR2RGB when the decoder delivered BGR) -> / 255 -> fp32 (out_h,out_w,3),
  * i.e. one image slot of the network's NHWC input batch.
  * Replaces /root/reference/utils.py:11-15 (cvtColor, resize, image / 255.); file decoding stays on the host.
- * Parity unpinned: OpenCV is absent, the kernel follows the published 8-bit INTER_LINEAR definition as restated in
- * yolo_amd/utils.py:resize_bilinear_u8 and is bit-identical to that restatement.
+ * Parity unpinned: OpenCV is absent and the reference holds no resized image; the kernel restates OpenCV's generic
+ * 8-bit INTER_LINEAR arithmetic (float32 coordinates, 11-bit coefficients, truncating two-pass form, 2x2 area average
+ * for an exact 2x downscale) and is bit-identical to the checker's restatement oracle/resize_ref.py.
  */
 int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int swap_rb, float *out, int out_h, int out_w,
                       ty1_stream_t stream);

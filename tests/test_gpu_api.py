@@ -212,14 +212,14 @@ def test_detection_records_roundtrip_on_device():
 
 
 # ------------------------------------------------------------------------------- preprocessing on the GPU (8f row 2)
-@pytest.mark.parametrize('h0,w0', [(448, 448), (375, 500), (37, 1000), (1080, 1920), (2, 3), (449, 447)])
-def test_preprocess_u8_equals_host_restatement(h0, w0):
-    """ty1_preprocess_u8 against yolo_amd.utils.resize_bilinear_u8 (the stated cv2 INTER_LINEAR 8-bit definition;
-    parity unpinned: OpenCV is not installed) followed by the reference's `image / 255.` in float64: bit-exact."""
-    from yolo_amd import ops
-    from yolo_amd.utils import resize_bilinear_u8
+@pytest.mark.parametrize('h0,w0', [(448, 448), (375, 500), (37, 1000), (1080, 1920), (2, 3), (449, 447), (896, 896)])
+def test_preprocess_u8_vs_oracle(h0, w0):
+    """ty1_preprocess_u8 against the checker's restatement of OpenCV's 8-bit INTER_LINEAR resize (oracle/resize_ref.py)
+    followed by the reference's `image / 255.` in float64 (/root/reference/utils.py:13-15): bit-exact.
+    PARITY UNPINNED with cv2 itself: OpenCV is not installed and the reference holds no resized image."""
+    from oracle.resize_ref import resize_linear_u8_ref, load_img_ref
     img = np.random.default_rng(h0 + w0).integers(0, 256, (h0, w0, 3), dtype=np.uint8)
-    want = (resize_bilinear_u8(img, 448, 448) / 255.).astype(np.float32)
+    want = load_img_ref(img, (448, 448, 3)).astype(np.float32)
     d = torch.from_numpy(img).to(DEV)
     got = ops.preprocess_u8(d, (448, 448)).cpu().numpy()
     assert np.array_equal(got, want)
@@ -228,11 +228,12 @@ def test_preprocess_u8_equals_host_restatement(h0, w0):
     # into one slot of a batch, other output size
     batch = torch.zeros((3, 224, 224, 3), device=DEV)
     ops.preprocess_u8(d, (224, 224), out=batch[1])
-    assert np.array_equal(batch[1].cpu().numpy(), (resize_bilinear_u8(img, 224, 224) / 255.).astype(np.float32))
+    assert np.array_equal(batch[1].cpu().numpy(), (resize_linear_u8_ref(img, 224, 224) / 255.).astype(np.float32))
     assert not batch[0].any() and not batch[2].any()
 
 
 def test_detect_from_file_uses_device_preprocessing(tmp_path):
+    """Regression check between the two product paths (file -> GPU preprocessing, host load_img -> upload)."""
     from PIL import Image
     from yolo_amd.tiny_yolov1 import TinyYOLOv1
     from yolo_amd.utils import load_img
@@ -245,3 +246,82 @@ def test_detect_from_file_uses_device_preprocessing(tmp_path):
     from_array = det.detect(host_img)
     assert len(from_file) == 1 and np.array_equal(from_file[0]['slots'], from_array[0]['slots'])
     assert np.array_equal(from_file[0]['boxes'], from_array[0]['boxes'])
+
+
+# ------------------------------------------------------------------------------- the other next rows (8f 1, 3, 4) on the GPU
+def test_darknet_weights_file_into_device_model(tmp_path):
+    """8f row 1: a full-size Darknet .weights file (layout /root/reference/convert.py:59-60,99-144,211-229) written by
+    the test, read by position with the generated cfg, runs in the HIP model exactly like the parameters it was
+    written from."""
+    from yolo_amd import darknet
+    prm = P.make_random_params(seed=7, dense_init='spread', bn='random')
+    specs = [(ci, co, i < P.N_POOL) for i, (ci, co) in enumerate(P.CONV_CHANNELS)]
+    cfg, wts = str(tmp_path / 'tiny.cfg'), str(tmp_path / 'tiny.weights')
+    darknet.write_cfg(cfg, specs, 448, 1470)
+    darknet.write_darknet_weights(wts, prm, specs)
+    loaded, size, got_specs = darknet.load_darknet_weights(cfg, wts)
+    assert size == 448 and got_specs == specs and loaded['floats_read'] == 27_099_950
+    assert all(np.array_equal(loaded[k], prm[k]) for k in prm)
+    x = torch.rand((2, 448, 448, 3), generator=torch.Generator().manual_seed(2)).to(DEV)
+    a = DeviceModel({k: v for k, v in loaded.items() if k in prm}, device=DEV, conv_specs=got_specs, img_size=size)
+    b = DeviceModel(prm, device=DEV)
+    assert torch.equal(a.predict(x), b.predict(x))
+    assert all(torch.equal(u, v) for u, v in zip(a.detect(x), b.detect(x)))
+
+
+def test_label_encoder_output_feeds_the_loss_kernel():
+    """8f row 3: y_true written by the reference's own SequenceData.read (tests/golden/labels_c20.npz) and the same
+    lines encoded here go through ty1_yolo_loss_fwd_bwd and give the oracle's loss and gradient."""
+    from yolo_amd.data_sequence import encode_boxes, parse_annotation_line
+    g = load_golden('labels_c20.npz')
+    y_true = np.stack([encode_boxes(parse_annotation_line(str(ln))[1], int(h), int(w), 7, 20)
+                       for ln, (h, w) in zip(g['lines'], g['hw'])]).astype(np.float32)        # Keras casts float64 labels
+    assert np.array_equal(y_true, g['label_matrix'].astype(np.float32))
+    N = y_true.shape[0]
+    z = np.random.default_rng(11).standard_normal((N, 1470)).astype(np.float32)
+    y_pred = model_ref.head_activate_ref(z)
+    loss_want, per_want, grad_want = loss_ref.yolo_loss_and_grad_ref(y_true, y_pred)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    loss, per, grad = ops.yolo_loss_fwd_bwd(d(y_true), d(y_pred))
+    assert abs(loss.item() - loss_want) <= 1e-5 * abs(loss_want)
+    np.testing.assert_allclose(per.cpu().numpy(), per_want, rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), grad_want, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name,C,img', [('nms_c20.npz', 20, 448), ('nms_c1.npz', 1, 224)])
+def test_detection_consumer_emits_what_the_reference_draws(name, C, img):
+    """8f row 4: ty1_decode_nms -> detections.batch_records against the cv.rectangle / cv.putText calls the reference's
+    _main made on the same predictions (/root/reference/tiny_yolov1.py:142-160: int() corners + class name;
+    /root/reference/faces/testFace.py:144-152: int() corners + str(confidence))."""
+    from yolo_amd.detections import batch_records, VOC_CLASSES
+    g = load_golden(name)
+    det = ops.decode_nms(torch.from_numpy(g['prediction']).to(DEV), 2, C, img)
+    recs = batch_records(det, img_size=img, names=VOC_CLASSES if C == 20 else None)
+    assert len(recs) == g['prediction'].shape[0]
+    for i, rl in enumerate(recs):
+        lo, hi = g['rect_off'][i], g['rect_off'][i + 1]
+        assert [r['corners'] for r in rl] == [tuple(int(v) for v in row) for row in g['rects'][lo:hi]], i
+        if C == 20:
+            assert [r['name'] for r in rl] == [ty.classes_name[k] for k in g['labels'][lo:hi]]
+            assert [r['class_id'] for r in rl] == list(g['labels'][lo:hi])
+        else:
+            assert [str(np.float32(r['score'])) for r in rl] == list(g['conf_str'][lo:hi])
+        assert all(r['box'] == tuple(float(v) for v in det[0][i, r['slot']].cpu().numpy()) for r in rl)   # no image_hw: same frame
+
+
+def test_train_compile_save_reload_keeps_trained_weights(tmp_path):
+    """Advisor finding: compile() after training drops the trainer; save_weights must still write the trained Dense."""
+    outputs, inputs = model_tiny_YOLOv1()
+    model = Model(inputs=inputs, outputs=outputs)
+    model.compile(loss=yolo_loss, optimizer=Adam(lr=0.001))
+    x = torch.rand((2, 448, 448, 3), generator=torch.Generator().manual_seed(5)).numpy()
+    y = _labels(2, 20, 2)
+    before = model.predict(x)
+    model.train_on_batch(x, y)
+    model.compile(loss=yolo_loss, optimizer=Adam(lr=0.0005))         # e.g. a new learning rate
+    after = model.predict(x)
+    assert not np.array_equal(before, after)
+    model.save_weights(str(tmp_path / 't.npz'))
+    m2 = Model(inputs=inputs, outputs=outputs, seed=42)
+    m2.load_weights(str(tmp_path / 't.npz'))
+    np.testing.assert_array_equal(m2.predict(x), after)

@@ -140,6 +140,52 @@ def test_model_bf16_end_to_end(dense_init):
     assert np.array_equal(boxes.view(np.uint64), np.ascontiguousarray(want['boxes']).view(np.uint64))
 
 
+def test_model_bf16_full_batch_properties():
+    """BASELINE configs[2] at its per-GPU size (128 images, bf16), where the oracle would take minutes: size-independent
+    properties.  The batch-128 launch shapes (other tile configurations than at N <= 70, K-split tails, fix-ups, the
+    bf16 Dense at 128 rows) are the ones the 8-GPU bench runs per rank and that the small cases above do not reach."""
+    import oracle
+    from yolo_amd.engine import DeviceModel
+    N = 128
+    prm = P.make_random_params(seed=1, C=20, dense_init='glorot', bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(0))
+    model = DeviceModel(prm, C=20, device=DEV, dtype='bf16')
+    xd = x.to(DEV)
+    y = model.predict(xd).clone()
+    ws = model.workspace(N)
+    z = (ws['part'].sum(0)[:, :model.units] + model.dense_b).clone()
+    # determinism: fixed-order reductions, a second run gives the same bits
+    assert torch.equal(model.predict(xd), y)
+    # three images of the batch against the oracle that rounds where the build rounds (stated bf16 tolerance, as in
+    # test_model_bf16_end_to_end: Dense logits within 3 % of their RMS; head outputs within 0.08 of the fp32 oracle)
+    pick = [0, 63, 127]
+    xs = x[pick].numpy()
+    feats_a = model_ref.backbone_ref(xs, prm, bf16=True)
+    z_a = model_ref.dense_ref(feats_a, prm['dense_w'], prm['dense_b'], bf16=True)
+    rms = float(np.sqrt((z_a ** 2).mean()))
+    err = np.abs(z[pick].cpu().numpy() - z_a).max() / rms
+    print(f'N=128 bf16: logits rms {rms:.3f}, max err {err:.3e} rms')
+    assert err < 3e-2
+    y_b = model_ref.model_ref(xs, prm, 7, 2, 20)
+    assert np.abs(y[pick].cpu().numpy() - y_b).max() < 0.08
+    # batch independence: position in the batch and batch size only change fp32 summation order (K-split plans) and,
+    # through that, a bf16 rounding here and there: the same tolerance as against the oracle
+    for i in (0, 17, 127):
+        model.predict(xd[i:i + 1].contiguous())
+        zi = model.workspace(1)['part'].sum(0)[0, :model.units] + model.dense_b
+        assert (zi - z[i]).abs().max().item() / rms < 3e-2
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    yp = model.predict(xd[perm].contiguous())
+    assert (yp - y[perm]).abs().max().item() < 0.02
+    # detections at full batch: bit-exact against the oracle fed the GPU's own scores
+    y2 = model.predict(xd).cpu().numpy()
+    boxes, score, cls, keep = (t.cpu().numpy() for t in model.detect(xd))
+    want = oracle.decode_nms(y2, 2, 20, 448)
+    assert np.array_equal(keep, want['keep']) and np.array_equal(cls, want['cls'])
+    assert np.array_equal(score.view(np.uint32), want['score'].view(np.uint32))
+    assert np.array_equal(boxes.view(np.uint64), np.ascontiguousarray(want['boxes']).view(np.uint64))
+
+
 @pytest.mark.parametrize('N,units', [(1, 1470), (64, 1470), (128, 539), (33, 100)])
 def test_dense_bf16_vs_oracle(N, units):
     """ty1_dense_splitk_bf16 on bf16 operands against the fp32 matmul of the same rounded values: the products of

@@ -93,10 +93,30 @@ def test_darknet_weight_file_layout(tmp_path):
     out = tmp_path / 'rt.weights'
     darknet.write_darknet_weights(str(out), p, specs)
     assert out.read_bytes() == wpath.read_bytes()
-    # the real cfg parses to the reference's layer list
-    size, specs, units = darknet.conv_specs_from_cfg(darknet.parse_cfg(os.path.join(os.path.dirname(__file__), 'golden', 'yolov1-tiny.cfg'))) \
-        if os.path.exists(os.path.join(os.path.dirname(__file__), 'golden', 'yolov1-tiny.cfg')) else (448, None, 1470)
-    assert size == 448 and units == 1470
+
+
+REFERENCE_CFG = '/root/reference/cfg/yolov1-tiny.cfg'
+MODEL_SPECS = [(ci, co, i < P.N_POOL) for i, (ci, co) in enumerate(P.CONV_CHANNELS)]
+
+
+def test_darknet_cfg_of_the_model(tmp_path):
+    """The cfg the reference ships (/root/reference/cfg/yolov1-tiny.cfg:1-129, present in the build container only)
+    and a cfg generated here with the same section pattern both parse to the layer list the model file transcribes."""
+    gen = str(tmp_path / 'gen.cfg')
+    darknet.write_cfg(gen, MODEL_SPECS, 448, 1470)
+    paths = [gen] + ([REFERENCE_CFG] if os.path.exists(REFERENCE_CFG) else [])
+    for path in paths:
+        sections = darknet.parse_cfg(path)
+        assert [t for t, _ in sections].count('convolutional') == 8 and sections[-1][0] == 'detection'
+        size, specs, units = darknet.conv_specs_from_cfg(sections)
+        assert (size, specs, units) == (448, MODEL_SPECS, 1470), path
+        det = sections[-1][1]
+        assert (int(det['classes']), int(det['side']), int(det['num'])) == (20, 7, 2)
+    # a cfg the fused kernels do not cover is refused
+    bad = tmp_path / 'bad.cfg'
+    bad.write_text(open(gen).read().replace('size=3', 'size=5', 1))
+    with pytest.raises(ValueError, match='3x3'):
+        darknet.conv_specs_from_cfg(darknet.parse_cfg(str(bad)))
 
 
 def test_device_layout_helpers():
@@ -114,12 +134,27 @@ def test_utils_twins(tmp_path):
     xy, wh = np.array([[10., 20.]]), np.array([[4., 6.]], np.float32)
     mn, mx = X_Y_W_H_To_Min_Max(xy, wh)
     assert np.array_equal(mn, [[8., 17.]]) and np.array_equal(mx, [[12., 23.]])
-    # INTER_LINEAR definition: identity at equal size, exact 2x2 box average on a 2x downscale
+    # INTER_LINEAR as OpenCV computes it on 8-bit images: identity at equal size, 2x2 box average on an exact 2x downscale
     img = np.random.default_rng(2).integers(0, 256, (8, 12, 3), dtype=np.uint8)
     assert np.array_equal(resize_bilinear_u8(img, 12, 8), img)
     half = resize_bilinear_u8(img, 6, 4).astype(np.int64)
     box = img.reshape(4, 2, 6, 2, 3).astype(np.int64).sum((1, 3))
-    assert np.abs(half * 4 - box).max() <= 2
+    assert np.array_equal(half, (box + 2) >> 2)
+    # the product's host resize against the checker's restatement (oracle/resize_ref.py; parity with cv2 itself is
+    # unpinned: OpenCV is absent), and against plain float bilinear interpolation within the fixed-point error
+    from oracle.resize_ref import resize_linear_u8_ref
+    rng = np.random.default_rng(3)
+    for h, w, oh, ow in [(375, 500, 448, 448), (37, 100, 448, 448), (600, 450, 224, 224), (2, 3, 448, 448), (449, 447, 448, 448)]:
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = resize_bilinear_u8(im, ow, oh)
+        assert np.array_equal(got, resize_linear_u8_ref(im, ow, oh))
+        fy = np.clip((np.arange(oh) + 0.5) * h / oh - 0.5, 0, h - 1); fx = np.clip((np.arange(ow) + 0.5) * w / ow - 0.5, 0, w - 1)
+        y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        ty, tx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+        f = im.astype(np.float64)
+        ideal = (f[y0][:, x0] * (1 - tx) + f[y0][:, x1] * tx) * (1 - ty) + (f[y1][:, x0] * (1 - tx) + f[y1][:, x1] * tx) * ty
+        assert np.abs(got - ideal).max() <= 1.0
     from PIL import Image
     Image.fromarray(img).save(str(tmp_path / 'a.png'))
     im, h, w = load_img(str(tmp_path / 'a.png'), (448, 448, 3))
@@ -149,6 +184,70 @@ def test_label_encoder_vs_reference_goldens():
     for i, ((h, w), want) in enumerate(zip(g['hw'], g['label_matrix'])):
         boxes = g['boxes'][g['box_off'][i]:g['box_off'][i + 1]]
         assert np.array_equal(encode_boxes(boxes, int(h), int(w), 7, 1), want)
+
+
+def test_label_encoder_single_class_twins_vs_reference_goldens(tmp_path):
+    """SequenceForFaces.read (/root/reference/data_sequence.py:248-287: xml corners, float, shifted by -1) and
+    SequenceForCelebA.read (:353-395: xywh -> corners, -1, swap on negative sizes), goldens written by the reference's
+    own methods (tests/golden/make_golden_labels.py): bit-exact."""
+    from conftest import load_golden
+    from yolo_amd.data_sequence import encode_boxes, voc_xml_boxes, celeba_box
+    g = load_golden('labels_faces.npz')
+    for i, ((h, w), want) in enumerate(zip(g['hw'], g['label_matrix'])):
+        rows = g['xml_corners'][g['box_off'][i]:g['box_off'][i + 1]]
+        xml = tmp_path / f'{i}.xml'
+        xml.write_text('<annotation><size><width>%d</width></size>' % w + ''.join(
+            '<object><name>face</name><bndbox><xmin>%r</xmin><ymin>%r</ymin><xmax>%r</xmax><ymax>%r</ymax></bndbox></object>'
+            % tuple(float(v) for v in r) for r in rows) + '</annotation>')
+        got = encode_boxes(voc_xml_boxes(str(xml)), int(h), int(w), 7, 1)
+        assert got.shape == (7, 7, 6) and np.array_equal(got, want), i
+    g = load_golden('labels_celeba.npz')
+    swapped = 0
+    for xywh, (h, w), want in zip(g['xywh'], g['hw'], g['label_matrix']):
+        box = celeba_box([int(v) for v in xywh])
+        swapped += int(xywh[2] < 0 or xywh[3] < 0)
+        assert box[0] <= box[2] and box[1] <= box[3]
+        assert np.array_equal(encode_boxes([box], int(h), int(w), 7, 1), want)
+    assert swapped >= 5                                   # the fixture exercises the swap branch
+
+
+def test_single_class_sequences_protocol(tmp_path):
+    """Constructors and record discovery of the three single-class loaders (data_sequence.py:111-129, :211-227,
+    :310-332) on a tiny synthetic directory tree."""
+    from PIL import Image
+    from yolo_amd.data_sequence import SequenceForAirplanes, SequenceForFaces, SequenceForCelebA
+    rng = np.random.default_rng(6)
+    img_dir, ann = tmp_path / 'img', tmp_path / 'ann'
+    (ann / 'train').mkdir(parents=True); (ann / 'val').mkdir(); (img_dir / 'a' / 'b' / 'c' / 'd').mkdir(parents=True)
+
+    def save(path, h=40, w=60):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(str(path))
+    # airplanes: csv + jpg with the same stem; names starting with 'airplane' train, with '4' validate
+    for n in ('airplane_001', 'airplane_002', '428483'):
+        (ann / f'{n}.csv').write_text('2\n5 6 30 20\n10 10 50 38\n')
+        save(img_dir / f'{n}.jpg')
+    seq = SequenceForAirplanes('train', str(ann), str(img_dir), (224, 224, 3), 2, shuffle=False)
+    assert len(seq.data_sets) == 2 and len(seq) == 1
+    X, y = seq[0]
+    assert X.shape == (2, 224, 224, 3) and y.shape == (2, 7, 7, 6) and y[..., 5].sum() == 4 and (y[..., 0] == y[..., 5]).all()
+    assert len(SequenceForAirplanes('val', str(ann), str(img_dir), (224, 224, 3), 2).data_sets) == 1
+    # faces: the first four '_' of the xml name are directory separators of the image path
+    (ann / 'train' / 'a_b_c_d_img_1.xml').write_text(
+        '<annotation><object><bndbox><xmin>11</xmin><ymin>6</ymin><xmax>31</xmax><ymax>26</ymax></bndbox></object></annotation>')
+    save(img_dir / 'a' / 'b' / 'c' / 'd' / 'img_1.jpg')
+    seq = SequenceForFaces('train', str(ann), str(img_dir), (224, 224, 3), 4, shuffle=False)
+    X, y = seq[0]
+    assert X.shape == (1, 224, 224, 3) and y[0, 2, 2, 5] == 1            # centre (20, 15) of a 60x40 image -> cell (2, 2)
+    assert np.allclose(y[0, 2, 2, 1:5], [7 * 20 / 60 - 2, 7 * 15 / 40 - 2, 20 / 60, 20 / 40])
+    # CelebA: two header lines, 80 / 20 split in file order
+    save(img_dir / '000001.jpg')
+    lst = tmp_path / 'list_bbox_celeba.txt'
+    lst.write_text('5\nimage_id x_1 y_1 width height\n' + ''.join(f'000001.jpg   {5 + i}  4 20  30\n' for i in range(5)))
+    tr = SequenceForCelebA('train', str(lst), str(img_dir), (224, 224, 3), 2)
+    va = SequenceForCelebA('val', str(lst), str(img_dir), (224, 224, 3), 2, shuffle=False)
+    assert len(tr.data_sets) == 4 and len(va.data_sets) == 1 and va.data_sets[0]['xywh'] == [9, 4, 20, 30]
+    X, y = va[0]
+    assert y.shape == (1, 7, 7, 6) and y[..., 5].sum() == 1
 
 
 def test_sequence_data_protocol(tmp_path):

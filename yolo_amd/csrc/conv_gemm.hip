@@ -860,14 +860,16 @@ void launch_c3(int nt, dim3 grid, hipStream_t s, const float *x, const float *w,
     }
 }
 
+// CU count of the CURRENT device, cached per device id (one process may drive several GPUs).
 int num_cus() {
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            return n;
-        return 256;
-    }();
-    return cus;
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
 }
 
 // How to run T equal tiles of C chunks each on `slots` CUs (see the header comment).  Costs are in chunk-times

@@ -3,11 +3,16 @@
 // image / 255. :15); decoding the file stays on the host.  SURVEY 8f row 2: at > 10 k images/s the host resize is the
 // bottleneck in front of the network.
 //
-// PARITY UNPINNED: OpenCV is not installed, so this follows the published definition of cv2.resize INTER_LINEAR on
-// 8-bit images (half-pixel centres: src = (dst + 0.5) * in/out - 0.5, edge clamp, coefficients rounded to 11 bits,
-// 22-bit product rounded half up) exactly as yolo_amd/utils.py:resize_bilinear_u8 restates it; the tests compare
-// this kernel with that host restatement bit for bit.
-// Compiled with -ffp-contract=off: the coordinate arithmetic is float64 in NumPy's operation order.
+// PARITY UNPINNED: OpenCV is not installed and the reference holds no resized image.  The kernel restates OpenCV's
+// generic 8-bit INTER_LINEAR path (the same restatement as oracle/resize_ref.py, which the tests compare it with bit
+// for bit, and yolo_amd/utils.py:resize_bilinear_u8):
+//   coordinates in float32 with half-pixel centres, s = floor(f), frac = f - s; the x axis snaps taps outside the row to
+//   the border pixel (frac = 0), the y axis clamps the two rows and keeps frac;
+//   11-bit coefficients short(rint((1 - frac) * 2048)), short(rint(frac * 2048));
+//   horizontal pass R = S[x0] * a0 + S[x1] * a1 in int32; vertical pass
+//   D = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
+//   an exact 2x downscale is OpenCV's 2x2 area average (a + b + c + d + 2) >> 2.
+// Compiled with -ffp-contract=off: the coordinate arithmetic must round as NumPy's does.
 #include "common.h"
 
 namespace {
@@ -15,17 +20,15 @@ namespace {
 struct Tap {
     int i0, i1, w0, w1;
 };
-__device__ __forceinline__ Tap tap_of(int o, int n_out, int n_in) {
-    const double f = ((double)o + 0.5) * ((double)n_in / (double)n_out) - 0.5;
-    const double fl = floor(f);
-    long long i0 = (long long)fl;
-    double frac = f - fl;
-    if (i0 < 0) frac = 0.0;
-    if (i0 >= n_in - 1) frac = 0.0;
-    const long long c0 = i0 < 0 ? 0 : (i0 > n_in - 1 ? n_in - 1 : i0);
-    const long long c1 = i0 + 1 < 0 ? 0 : (i0 + 1 > n_in - 1 ? n_in - 1 : i0 + 1);
-    const int w1 = (int)rint(frac * 2048.0);
-    return Tap{(int)c0, (int)c1, 2048 - w1, w1};
+__device__ __forceinline__ Tap tap_of(int o, int n_out, int n_in, bool x_axis) {
+    const float f = (float)(((double)o + 0.5) * ((double)n_in / (double)n_out) - 0.5);
+    const float fl = floorf(f);
+    float frac = f - fl;
+    const int s = (int)fl;
+    if (x_axis && (s < 0 || s >= n_in - 1)) frac = 0.f;
+    const int c0 = s < 0 ? 0 : (s > n_in - 1 ? n_in - 1 : s);
+    const int c1 = s + 1 < 0 ? 0 : (s + 1 > n_in - 1 ? n_in - 1 : s + 1);
+    return Tap{c0, c1, (int)rintf((1.f - frac) * 2048.f), (int)rintf(frac * 2048.f)};
 }
 
 // one thread per output pixel (3 channels): HBM-bound, 12 source bytes in and 12 bytes out per thread
@@ -34,15 +37,28 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char 
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= OH * OW) return;
     const int oy = idx / OW, ox = idx - oy * OW;
-    const Tap ty = tap_of(oy, OH, H0), tx = tap_of(ox, OW, W0);
+    const bool area2 = H0 == 2 * OH && W0 == 2 * OW;
+    Tap ty, tx;
+    if (area2) {
+        ty = Tap{2 * oy, 2 * oy + 1, 0, 0};
+        tx = Tap{2 * ox, 2 * ox + 1, 0, 0};
+    } else {
+        ty = tap_of(oy, OH, H0, false);
+        tx = tap_of(ox, OW, W0, true);
+    }
     const unsigned char *r0 = img + (size_t)ty.i0 * W0 * 3, *r1 = img + (size_t)ty.i1 * W0 * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int sc = swap_rb ? 2 - c : c;
-        const long long a = (long long)r0[tx.i0 * 3 + sc] * tx.w0 + (long long)r0[tx.i1 * 3 + sc] * tx.w1;
-        const long long b = (long long)r1[tx.i0 * 3 + sc] * tx.w0 + (long long)r1[tx.i1 * 3 + sc] * tx.w1;
-        const long long v = (a * ty.w0 + b * ty.w1 + (1ll << 21)) >> 22;
-        out[(size_t)idx * 3 + c] = (float)((double)v / 255.0);      // image / 255. in float64, then Keras' cast to fp32
+        const int p00 = r0[tx.i0 * 3 + sc], p01 = r0[tx.i1 * 3 + sc], p10 = r1[tx.i0 * 3 + sc], p11 = r1[tx.i1 * 3 + sc];
+        int v;
+        if (area2) {
+            v = (p00 + p01 + p10 + p11 + 2) >> 2;
+        } else {
+            const int a = (p00 * tx.w0 + p01 * tx.w1) >> 4, b = (p10 * tx.w0 + p11 * tx.w1) >> 4;
+            v = (((ty.w0 * a) >> 16) + ((ty.w1 * b) >> 16) + 2) >> 2;
+        }
+        out[(size_t)idx * 3 + c] = (float)((double)(v & 255) / 255.0);      // uchar(...), image / 255. in float64, Keras' cast to fp32
     }
 }
 

@@ -52,6 +52,21 @@ def conv_specs_from_cfg(sections):
     return size, [tuple(s) for s in specs], units
 
 
+def write_cfg(path, specs, img_size=448, units=1470, S=7, B=2, C=20):
+    """Write a Darknet cfg for a conv/maxpool/connected/detection stack: the section pattern of
+    /root/reference/cfg/yolov1-tiny.cfg generated from (cin, cout, pool) specs (the inverse of conv_specs_from_cfg;
+    training hyper-parameters of [net] are not part of the model and are left out)."""
+    out = [f'[net]\nbatch=1\nsubdivisions=1\nheight={img_size}\nwidth={img_size}\nchannels={specs[0][0]}\n']
+    for _, cout, pool in specs:
+        out.append(f'[convolutional]\nbatch_normalize=1\nfilters={cout}\nsize=3\nstride=1\npad=1\nactivation=leaky\n')
+        if pool:
+            out.append('[maxpool]\nsize=2\nstride=2\n')
+    out.append(f'[connected]\noutput= {units}\nactivation=linear\n')
+    out.append(f'[detection]\nclasses={C}\ncoords=4\nrescore=1\nside={S}\nnum={B}\nsoftmax=0\nsqrt=1\n')
+    with open(path, 'w') as f:
+        f.write('\n'.join(out))
+
+
 def load_darknet_weights(cfg_path, weights_path):
     """-> (params dict in Keras layouts, img_size, conv_specs)."""
     size, specs, units = conv_specs_from_cfg(parse_cfg(cfg_path))

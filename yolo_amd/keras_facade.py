@@ -116,6 +116,7 @@ class Model:
         self.params = self._init_params(seed)
         self._engine = None
         self._trainer = None
+        self._trained = False          # the engine's Dense weights are ahead of self.params (set by train_on_batch)
         self.loss, self.optimizer = None, None
 
     # ------------------------------------------------------------------ graph -> fused plan
@@ -185,6 +186,7 @@ class Model:
     def set_params(self, params):
         self.params = {k: np.ascontiguousarray(v, np.float32) for k, v in params.items()}
         self._engine = self._trainer = None
+        self._trained = False
 
     def _keras_names(self):
         """Keras weight names -> our parameter keys (for by_name loading)."""
@@ -209,6 +211,7 @@ class Model:
                 raise ImportError('HDF5 weights need h5py (absent here); use a .npz or a Darknet .weights file '
                                   '(yolo_amd.darknet.load_darknet_weights)') from e
             raise NotImplementedError('HDF5 reader not wired; use .npz / Darknet .weights')
+        self._pull_trained()             # by_name may load only part of the model: keep what training changed
         names = self._keras_names()
         loaded = []
         with np.load(path, allow_pickle=False) as z:
@@ -217,6 +220,7 @@ class Model:
                     self.params[names[k]] = np.ascontiguousarray(z[k], np.float32)
                     loaded.append(k)
         self._engine = self._trainer = None
+        self._trained = False
         return loaded
 
     def save_weights(self, path):
@@ -225,8 +229,11 @@ class Model:
         np.savez(path, **{inv[k]: v for k, v in self.params.items()})
 
     def _pull_trained(self):
-        if self._trainer is not None:
+        """Copy the trained Dense kernel / bias back from the device.  Keyed on "a step has run since the last pull",
+        not on the trainer object: compile() drops the trainer (new optimizer state) but the engine keeps the weights."""
+        if self._trained and self._engine is not None:
             eng = self._engine
+            self._trained = False
             self.params['dense_w'] = P.dense_from_device_layout(eng.dense_wt.cpu().numpy(), eng.units)
             self.params['dense_b'] = eng.dense_b.cpu().numpy()
 
@@ -266,6 +273,7 @@ class Model:
     def train_on_batch(self, x, y):
         """One optimizer step on (x, y_true); returns the batch-SUM loss as a float."""
         t = self._get_trainer()
+        self._trained = True
         return float(t.step(self._to_device(x), self._to_device(y)).item())
 
     def test_on_batch(self, x, y):

@@ -17,6 +17,14 @@ def _chk(t, dtype, name):
     return t
 
 
+def _chk_out(t, dtype, shape, name):
+    """A caller-provided output buffer: its raw pointer goes to a kernel, so type, device, layout and shape must fit."""
+    _chk(t, dtype, name)
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f'{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t
+
+
 def round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -156,7 +164,11 @@ def dense_splitk(x, wt, units, splits=None, part=None):
         part = torch.empty((splits, N, ldz), dtype=torch.float32, device=x.device)
     else:
         _chk(part, torch.float32, 'part')
+        if part.dim() != 3 or part.shape[1] != N or part.shape[2] < units:
+            raise ValueError(f'part: expected (splits, {N}, >= {units}), got {tuple(part.shape)}')
         splits, _, ldz = part.shape
+    if wt.shape[0] < units or ldk < K:
+        raise ValueError(f'wt: expected (>= {units}, >= {K}), got {tuple(wt.shape)}')
     _lib.call('ty1_dense_splitk_bf16' if bf else 'ty1_dense_splitk_f32', x.data_ptr(), wt.data_ptr(), part.data_ptr(), N, K, units, ldk, ldz,
               splits, _lib.current_stream())
     return part
@@ -170,8 +182,14 @@ def head_activate(part, bias, S=7, B=2, C=20, out=None):
     splits, N, ldz = part.shape
     if bias is not None:
         _chk(bias, torch.float32, 'bias')
+        if bias.numel() < S * S * (C + 5 * B):
+            raise ValueError(f'bias: expected {S * S * (C + 5 * B)} values, got {bias.numel()}')
+    if ldz < S * S * (C + 5 * B):
+        raise ValueError(f'part: last dimension {ldz} is smaller than the {S * S * (C + 5 * B)} Dense units')
     if out is None:
         out = torch.empty((N, S, S, C + 5 * B), dtype=torch.float32, device=part.device)
+    else:
+        _chk_out(out, torch.float32, (N, S, S, C + 5 * B), 'out')
     _lib.call('ty1_head_activate_f32', part.data_ptr(), _lib.ptr(bias), out.data_ptr(), N, S, B, C, ldz, splits,
               _lib.current_stream())
     return out
@@ -193,6 +211,8 @@ def decode_nms(pred, B=2, C=20, img_size=448, iou_thr=0.2, out=None):
                torch.empty((N, slots), dtype=torch.int32, device=dev),
                torch.empty((N, slots), dtype=torch.uint8, device=dev))
     boxes, score, cls, keep = out
+    _chk_out(boxes, torch.float64, (N, slots, 4), 'boxes'); _chk_out(score, torch.float32, (N, slots), 'score')
+    _chk_out(cls, torch.int32, (N, slots), 'cls'); _chk_out(keep, torch.uint8, (N, slots), 'keep')
     _lib.call('ty1_decode_nms', pred.data_ptr(), N, S, B, C, int(img_size), float(iou_thr),
               boxes.data_ptr(), score.data_ptr(), cls.data_ptr(), keep.data_ptr(), _lib.current_stream())
     return boxes, score, cls, keep
@@ -202,8 +222,13 @@ def pack_detections(boxes, score, cls, keep, out=None):
     """-> (N, slots, 6) f64 records x0,y0,x1,y1,score,class (-1 where not kept): the unit of the detection gather."""
     _chk(boxes, torch.float64, 'boxes'); _chk(score, torch.float32, 'score'); _chk(cls, torch.int32, 'cls'); _chk(keep, torch.uint8, 'keep')
     N, slots = score.shape
+    for name, t, shp in (('boxes', boxes, (N, slots, 4)), ('cls', cls, (N, slots)), ('keep', keep, (N, slots))):
+        if tuple(t.shape) != shp:
+            raise ValueError(f'{name}: expected shape {shp}, got {tuple(t.shape)}')
     if out is None:
         out = torch.empty((N, slots, 6), dtype=torch.float64, device=boxes.device)
+    else:
+        _chk_out(out, torch.float64, (N, slots, 6), 'out')
     _lib.call('ty1_pack_detections', boxes.data_ptr(), score.data_ptr(), cls.data_ptr(), keep.data_ptr(), out.data_ptr(),
               N * slots, _lib.current_stream())
     return out
@@ -274,8 +299,12 @@ def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True):
 def head_activate_bwd(y, grad_y, ldz, B=2, C=20, out=None):
     _chk(y, torch.float32, 'y'); _chk(grad_y, torch.float32, 'grad_y')
     N, S = y.shape[0], y.shape[1]
+    if tuple(grad_y.shape) != tuple(y.shape) or y.shape[-1] != C + 5 * B or ldz < y[0].numel():
+        raise ValueError(f'head_activate_bwd: y {tuple(y.shape)}, grad_y {tuple(grad_y.shape)}, ldz {ldz} do not fit B={B}, C={C}')
     if out is None:
         out = torch.empty((N, ldz), dtype=torch.float32, device=y.device)
+    else:
+        _chk_out(out, torch.float32, (N, ldz), 'out')
     _lib.call('ty1_head_activate_bwd_f32', y.data_ptr(), grad_y.data_ptr(), out.data_ptr(), N, S, B, C, ldz,
               _lib.current_stream())
     return out
@@ -284,6 +313,9 @@ def head_activate_bwd(y, grad_y, ldz, B=2, C=20, out=None):
 def dense_wgrad(dz, x, units, dwt, db):
     _chk(dz, torch.float32, 'dz'); _chk(x, torch.float32, 'x'); _chk(dwt, torch.float32, 'dwt'); _chk(db, torch.float32, 'db')
     N, K = x.shape
+    if dz.shape[0] != N or dz.shape[1] < units or dwt.shape[0] < units or dwt.shape[1] < K or db.numel() < units:
+        raise ValueError(f'dense_wgrad: dz {tuple(dz.shape)}, x {tuple(x.shape)}, dwt {tuple(dwt.shape)}, db {tuple(db.shape)} '
+                         f'do not fit units={units}')
     _lib.call('ty1_dense_wgrad_f32', dz.data_ptr(), x.data_ptr(), dwt.data_ptr(), db.data_ptr(), N, K, units,
               dwt.shape[1], dz.shape[1], _lib.current_stream())
     return dwt, db
