@@ -5,14 +5,21 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path over one batch of synthetic images already resident in HBM.
-At N=1 the workload is BASELINE.json configs[1]: batch 64, fp32, one MI355X.  For N>1 every rank
-runs the same per-GPU batch (weak scaling: the path shards by image with no data-path collective)
-and the fixed-size detection records are all-gathered (configs[2]'s "detection gather").
-Prints ONE JSON line on rank 0.
+The contract line (ONE JSON line on rank 0) is BASELINE.json configs[1]: batch 64 per GPU, fp32; for N > 1
+every rank runs the same per-GPU batch (weak scaling: the path shards by image with no data-path collective) and the
+fixed-size detection records are all-gathered inside the step.
+
+The same line carries, under "also", the two BASELINE.json configs that are multi-GPU by definition, measured in the
+same process right after the headline (skip with --no-also):
+  configs[2]  bf16 inference, 128 images per GPU (1024 over 8), detection gather inside the step when N > 1
+  configs[3]  VOC-20 training step, 32 images per GPU: frozen backbone fwd + Dense + yolo_loss fwd/bwd + wgrad +
+              ONE SUM all-reduce (overlapped with the next batch's backbone) + Adam
+Either can be made the headline instead: --mode infer --dtype bf16, or --mode train.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -22,42 +29,376 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+# /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks (no sparsity) and HBM3E
+PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}
 PEAK_HBM_GBS = 8000.0
+GFLOP_PER_IMAGE = 3.216          # 2 x 1,608,015,360 MACs
 
-# libty1 event-timer name -> kernel symbol as rocprofv3 --kernel-trace prints it
+# libty1 event-timer family -> kernel symbol as rocprofv3 --kernel-trace prints it (profiles/pmc_traffic*.json keys)
 _CFG = {'128x128': '2, 2, 2, 2, 32', '128x64': '2, 1, 2, 2, 32', '64x64': '1, 1, 2, 2, 32', '256x32': '2, 1, 4, 1, 32',
-        'bk16_128x64': '2, 1, 2, 2, 16', 'bk16_256x32': '2, 1, 4, 1, 16'}
+        'bk16_128x64': '2, 1, 2, 2, 16', 'bk16_256x32': '2, 1, 4, 1, 16', '256x128': '2, 2, 4, 2, 32', '256x64': '2, 1, 4, 2, 32'}
 ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv3x3_c16_pool': 'conv3x3_c16_kernel<true, 1>',
+                  'conv3x3_c3_pool_bf16out': 'conv3x3_c3p_kernel<true, 1, true>',
                   'dense_f32_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2, 4>',
                   'dense_f32_32x128': 'dense_gemm_f32_kernel<1, 1, 1, 4, 4>',
                   'decode_nms': 'decode_nms_kernel<2>', 'head_activate': 'head_activate_kernel'}
 for _k, _v in _CFG.items():
     ROCPROF_SYMBOL[f'conv_f32_{_k}_pool'] = f'conv_persist_kernel<{_v}, true, OpF32, false>'
     ROCPROF_SYMBOL[f'conv_f32_{_k}'] = f'conv_persist_kernel<{_v}, false, OpF32, false>'
+    ROCPROF_SYMBOL[f'conv_bf16_{_k}_pool'] = f'conv_persist_kernel<{_v}, true, OpBF16, true>'
+    ROCPROF_SYMBOL[f'conv_bf16_{_k}'] = f'conv_persist_kernel<{_v}, false, OpBF16, true>'
 
 
-def cpu_baseline(prm, x_cpu, seconds, C=20):
-    """The oracle (CPU restatement of the reference Keras path + NumPy post-processing) timed on the
-    host cores of this box: a reported baseline, not the target.  Bounded sample: the synthetic batch is
-    walked in chunks of 8 images, again and again, until `seconds` of CPU work have been timed."""
+class Ctx:
+    """Process-wide state: rank / world, device, the process group when there is one."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if self.world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device('cuda', self.local_rank)
+        self.multi = self.world > 1 or args.force_gather
+        self.dist = None
+        self.rccl_world = 1
+        if self.multi:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', device_id=self.dev, rank=self.rank, world_size=self.world)
+            self.dist = dist
+            self.rccl_world = dist.get_world_size()       # what RCCL's communicator reports, not the env
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+        if self.multi:
+            self.dist.barrier(device_ids=[self.local_rank])
+            torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if not self.multi:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.multi:
+            self.dist.barrier(device_ids=[self.local_rank])
+            self.dist.destroy_process_group()
+
+
+def settle(ctx, step, settle_ms, est_step_ms):
+    """The shader clock of this chip climbs for tens of milliseconds after it leaves idle ("Clocks"): the
+    same kernels run 10-12 % slower in the first few ms.  The metric is steady-state throughput, so untimed steps
+    continue until the GPU has been busy for `settle_ms` before the timed region; the count is reported."""
+    n = 0
+    if settle_ms <= 0:
+        return 0
+    if ctx.multi:       # every rank must issue the same number of collectives: a fixed count, not a local clock
+        n = max(1, int(settle_ms / max(est_step_ms, 0.05)))
+        for _ in range(n):
+            step()
+    else:
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < settle_ms and n < 4000:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(ctx.dev)
+            n += 10
+    ctx.sync()
+    return n
+
+
+def timed(ctx, step, k):
+    """Exactly k steps between barrier + synchronise on both sides; MAX over ranks."""
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    ctx.sync()
+    return ctx.max_over_ranks(time.perf_counter() - t0)
+
+
+def families(table):
+    """Per-layer timer entries are named '<kernel>@<H>x<Cin>><Cout>'; rocprofv3 --stats aggregates per kernel symbol,
+    so fold the layers of one instantiation together."""
+    fam = {}
+    for k, v in table.items():
+        e = fam.setdefault(k.split('@')[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for f in e:
+            e[f] += v[f]
+    return fam
+
+
+def kernel_rows(table):
+    gpu_ms = sum(v['ms'] for v in table.values()) or 1.0
+    rows = {}
+    for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+        rows[k] = {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / max(v['launches'], 1), 2),
+                   'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 and v['flops'] > 0 else None,
+                   'algo_gbs': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 and v['bytes'] > 0 else None,
+                   'share': round(v['ms'] / gpu_ms, 3)}
+    return rows
+
+
+def traffic_of(dom_name, dtype, mode):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command (tools/profile.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    fname = {('infer', 'f32'): 'pmc_traffic.json', ('infer', 'bf16'): 'pmc_traffic_bf16.json',
+             ('train', 'f32'): 'pmc_traffic_train.json'}.get((mode, dtype))
+    try:
+        pj = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+        sym = (ROCPROF_SYMBOL.get(dom_name) or '').replace('(anonymous namespace)::', '')
+        cands = [sym, sym.replace('OpBF16, true>', 'OpBF16, false>')]
+        for c in cands:
+            if c in pj['kernels']:
+                e = pj['kernels'][c]
+                return round(e['hbm_read_bytes'] + e['hbm_write_bytes']), pj['source']
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_of(dom_name, dom, dtype, mode):
+    """dom: launches / ms / flops / bytes of the dominant kernel measured live inside the timed region."""
+    secs = dom['ms'] * 1e-3
+    ai = dom['flops'] / max(dom['bytes'], 1.0)
+    ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    traffic, src = traffic_of(dom_name, dtype, mode)
+    common = {'kernel': dom_name, 'rocprof_symbol': ROCPROF_SYMBOL.get(dom_name), 'traffic': traffic,
+              'traffic_unit': 'HBM bytes per launch', 'traffic_source': src, 'launches': dom['launches'],
+              'avg_launch_us': round(1e3 * dom['ms'] / max(dom['launches'], 1), 2),
+              'algo_flops_per_launch': dom['flops'] / max(dom['launches'], 1),
+              'algo_bytes_per_launch': dom['bytes'] / max(dom['launches'], 1),
+              'arithmetic_intensity': round(ai, 1), 'ridge': round(ridge, 1)}
+    if ai >= ridge:
+        a = dom['flops'] / secs / 1e12
+        return {'bound': 'mfma', 'achieved': round(a, 2), 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
+                'frac': round(a / PEAK_TFLOPS[dtype], 4), **common}
+    a = dom['bytes'] / secs / 1e9
+    return {'bound': 'hbm', 'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4), **common}
+
+
+def measure(ctx, step, args, dtype, mode, est_step_ms, detailed=True):
+    """Warm-up, cold figure, settle, survey pass, timed region (dominant kernel bracketed live), plain repeat."""
+    from yolo_amd import ops
+    for _ in range(args.warmup):
+        step()
+    cold = timed(ctx, step, args.steps)                     # straight after the W warm-up steps: clocks still ramping
+    settle_steps = settle(ctx, step, args.settle_ms, est_step_ms)
+    table, dom_name = {}, None
+    if detailed:
+        # survey pass (untimed): every library launch brackets itself with HIP events on its own stream -> per-kernel
+        # table, names the dominant kernel.  Bracketing EVERY launch costs ~5 % of a step, so the timed region below
+        # keeps the brackets on the dominant kernel's launches only.
+        with ops.KernelTimer() as kt:
+            for _ in range(args.steps):
+                step()
+            ctx.sync()
+            table = kt.table()
+        fam = families(table)
+        dom_name = max(fam, key=lambda k: fam[k]['ms'])
+    prefix = None
+    if dom_name is not None:
+        prefix = dom_name + '@' if any(k.startswith(dom_name + '@') for k in table) else dom_name
+    with ops.KernelTimer(only=prefix or 'none') as kt:
+        elapsed = timed(ctx, step, args.steps)              # ---- THE timed region: exactly K steps
+    # un-instrumented repeat, back to back with the timed region (host-side table work comes after it)
+    plain = timed(ctx, step, args.steps)
+    live = kt.table()
+    out = {'elapsed': elapsed, 'plain': plain, 'cold': cold, 'settle_steps': settle_steps, 'table': table}
+    if dom_name is not None:
+        dom = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)
+        for k, v in live.items():
+            if k.split('@')[0] == dom_name:
+                for f in dom:
+                    dom[f] += v[f]
+        if dom['launches'] and dom['ms'] > 0:
+            out['roofline'] = roofline_of(dom_name, dom, dtype, mode)
+            mm = {k: v for k, v in table.items() if v['flops'] > 0 and v['ms'] > 0}
+            out['roofline']['all_matmul_kernels_tflops'] = round(
+                sum(v['flops'] for v in mm.values()) / (sum(v['ms'] for v in mm.values()) * 1e-3) / 1e12, 2)
+    return out
+
+
+def synthetic_images(n, seed, dev):
+    return torch.rand((n, 448, 448, 3), generator=torch.Generator(device='cpu').manual_seed(seed))
+
+
+def run_infer(ctx, args, dtype, N, detailed=True):
+    from yolo_amd import ops, params as P
+    from yolo_amd.engine import DeviceModel
+    C = 20
+    prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
+    model = DeviceModel(prm, C=C, device=ctx.dev, dtype=dtype)
+    x_cpu = synthetic_images(N, 0, ctx.dev)
+    x = x_cpu.to(ctx.dev)
+    model.workspace(N)
+    rec = gathered = None
+    if ctx.multi:
+        rec = torch.empty((N, 98, 6), dtype=torch.float64, device=ctx.dev)          # box(4) score cls*keep
+        gathered = torch.empty((ctx.world * N, 98, 6), dtype=torch.float64, device=ctx.dev)
+    state = {}
+
+    def step():
+        boxes, score, cls, keep = model.detect(x)
+        if ctx.multi:                                  # detection gather: fixed-size records, one collective
+            ops.pack_detections(boxes, score, cls, keep, out=rec)
+            ctx.dist.all_gather_into_tensor(gathered, rec)
+        state['keep'] = keep
+
+    est = 1.65 if dtype == 'f32' else 0.8
+    m = measure(ctx, step, args, dtype, 'infer', est * N / (64 if dtype == 'f32' else 128), detailed)
+    kept = float(state['keep'].sum().item()) / N
+    K, world = args.steps, ctx.world
+    res = {
+        'value': round(world * N * K / m['elapsed'], 1), 'unit': 'images/sec',
+        'ms_per_step': round(1e3 * m['elapsed'] / K, 4), 'settle_steps': m['settle_steps'],
+        'dtype': dtype,
+        'config': {'workload': (f'configs[1]: tiny-YOLOv1 448x448 batch={N}/GPU fp32' if dtype == 'f32' else
+                                f'configs[2]: tiny-YOLOv1 448x448 batch={N}/GPU bf16 (conv + Dense operands bf16, fp32 accumulate)')
+                               + ' backbone+Dense+head+decode+NMS, random-init weights (glorot, identity BN: dense-candidate '
+                                 'NMS stress), torch.rand images resident in HBM',
+                   'global_batch': world * N, 'per_gpu_batch': N,
+                   'sharding': 'batch split across ranks, no data-path collective'
+                               + ('; all-gather of fixed-size detection records inside the step' if ctx.multi else ''),
+                   'kept_boxes_per_image': round(kept, 2)},
+        'repeat_without_events_images_per_sec': round(world * N * K / m['plain'], 1),
+        'cold_start_images_per_sec': round(world * N * K / m['cold'], 1),
+        'cold_start_note': f'the same K steps timed straight after the {args.warmup} warm-up steps, before the '
+                           f'{args.settle_ms:.0f} ms settle phase (shader clock still ramping)',
+        'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS[dtype] * 1e12), 4),
+    }
+    if ctx.multi:
+        res['rccl'] = {'backend': 'nccl (RCCL)', 'world_size_reported': ctx.rccl_world,
+                       'gathered_records_shape': list(gathered.shape),
+                       'gathered_kept_boxes': int((gathered[..., 5] >= 0).sum().item())}
+    if 'roofline' in m:
+        res['roofline'] = m['roofline']
+    if detailed:
+        res['kernels'] = kernel_rows(m['table'])
+    return res, prm, x_cpu
+
+
+def make_labels(N, C, seed):
+    """SURVEY 8d training labels: 3 objects per image, uniform cell and class, first writer wins (data_sequence.py:79-85)."""
+    rng = np.random.default_rng(seed)
+    y = np.zeros((N, 7, 7, C + 5), np.float32)
+    for n in range(N):
+        for _ in range(3):
+            r, c, k = rng.integers(7), rng.integers(7), rng.integers(C)
+            if y[n, r, c, C + 4] == 0:
+                y[n, r, c, k] = 1
+                y[n, r, c, C:C + 4] = rng.random(4)
+                y[n, r, c, C + 4] = 1
+    return y
+
+
+def run_train(ctx, args, N, detailed=True):
+    from yolo_amd import params as P
+    from yolo_amd.engine import DeviceModel, Trainer
+    C = 20
+    prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')
+    model = DeviceModel(prm, C=C, device=ctx.dev)
+    x = synthetic_images(N, 100 + ctx.rank, ctx.dev).to(ctx.dev)
+    yd = torch.from_numpy(make_labels(N, C, 3 + ctx.rank)).to(ctx.dev)
+    tr = Trainer(model, group=None, overlap=not args.no_overlap)
+    state = {}
+
+    def step():
+        state['loss'] = tr.step(x, yd, wait=False)     # exchange + Adam stay in flight under the next backbone
+
+    tr.bucket.always = ctx.multi                       # --force-gather: the collective runs on one rank too
+    real_sync = ctx.sync
+    ctx.sync = lambda: (tr.join(), real_sync())[1]
+    try:
+        m = measure(ctx, step, args, 'f32', 'train', 1.3 * N / 32, detailed)
+        K, world = args.steps, ctx.world
+        # the exchange by itself: device time of the collective (events on the side stream, short separate pass) and
+        # the step time with the collective left out (what the exchange costs after overlap = "exposed")
+        tr.time_collective = True
+        coll_ms = []
+        for _ in range(5):
+            step()
+            ctx.sync()
+            if tr.collective_events:
+                coll_ms.append(tr.collective_events[0].elapsed_time(tr.collective_events[1]))
+        tr.time_collective = False
+        tr.skip_collective = True
+        for _ in range(3):
+            step()
+        no_coll = timed(ctx, step, K)
+        tr.skip_collective = False
+    finally:
+        ctx.sync = real_sync
+    nbytes = tr.bucket.nbytes()
+    coll = statistics.median(coll_ms) if coll_ms else 0.0
+    res = {
+        'value': round(world * N * K / m['elapsed'], 1), 'unit': 'images/sec',
+        'steps_per_sec': round(K / m['elapsed'], 2),
+        'ms_per_step': round(1e3 * m['elapsed'] / K, 4), 'settle_steps': m['settle_steps'], 'dtype': 'f32',
+        'config': {'workload': f'configs[3]: tiny-YOLOv1 VOC-20 training step, batch={N}/GPU fp32: frozen backbone fwd + Dense + '
+                               'head + yolo_loss fwd/bwd + head bwd + Dense wgrad + ONE SUM all-reduce [dWt|db|loss] + Adam; '
+                               'random-init weights, torch.rand images and synthetic labels resident in HBM',
+                   'global_batch': world * N, 'per_gpu_batch': N,
+                   'sharding': 'batch split across ranks (data parallel), gradients summed (no division: the loss is a batch sum)',
+                   'overlap': 'all-reduce + Adam on a side stream under the next batch\'s frozen backbone'
+                              if not args.no_overlap else 'serial'},
+        'loss': float(state['loss'].item()),
+        'allreduce': {'collectives_per_step': 1 if world > 1 or ctx.multi else 0, 'message_bytes': nbytes,
+                      'device_ms': round(coll, 4),
+                      'bus_GBps': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if coll > 0 and world > 1 else None,
+                      'ms_per_step_without_collective': round(1e3 * no_coll / K, 4),
+                      'exposed_ms': round(1e3 * (m['elapsed'] - no_coll) / K, 4),
+                      'share_of_step': round(max(0.0, (m['elapsed'] - no_coll) / m['elapsed']), 4)},
+        'repeat_without_events_images_per_sec': round(world * N * K / m['plain'], 1),
+        'cold_start_images_per_sec': round(world * N * K / m['cold'], 1),
+        'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS['f32'] * 1e12), 4),
+    }
+    if ctx.multi:
+        res['rccl'] = {'backend': 'nccl (RCCL)', 'world_size_reported': ctx.rccl_world}
+    if 'roofline' in m:
+        res['roofline'] = m['roofline']
+    if detailed:
+        res['kernels'] = kernel_rows(m['table'])
+    return res
+
+
+def cpu_baseline(prm, x_cpu, budget_s, C=20):
+    """The oracle (CPU restatement of the reference Keras path + C restatement of its NumPy decode/NMS) timed on the host
+    cores of this box: a reported baseline, not the target.  Protocol of BASELINE.md 4 / SURVEY 8d: N = 1 and N = 64,
+    3 warm-ups, median of >= 10 runs; the run counts shrink (and say so) only if the host is too slow for the budget."""
     import oracle
     from oracle import model_ref
-    threads = torch.get_num_threads()
     x = x_cpu.numpy()
-    bs = 8
-    model_ref.model_ref(x[:2], prm, 7, 2, C)                       # warm-up
-    t0 = time.perf_counter()
-    done = kept = 0
-    while time.perf_counter() - t0 < seconds:
-        i = done % max(x.shape[0] - bs + 1, 1)
-        y = model_ref.model_ref(x[i:i + bs], prm, 7, 2, C)
-        kept += int(oracle.decode_nms(y, 2, C, 448)['keep'].sum())
-        done += min(bs, x.shape[0] - i)
-    dt = time.perf_counter() - t0
-    return {'value': done / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{done} images ({dt:.1f} s of CPU work) drawn in chunks of {bs} from the same synthetic batch: torch-CPU fp32 '
-                      f'restatement of the reference Keras model + C restatement of its NumPy decode/NMS'}
+
+    def one(n):
+        t0 = time.perf_counter()
+        y = model_ref.model_ref(x[:n], prm, 7, 2, C)
+        oracle.decode_nms(y, 2, C, 448)
+        return time.perf_counter() - t0
+
+    def protocol(n, budget):
+        first = one(n)
+        warm = 3 if first * 13 < budget else 1
+        for _ in range(warm - 1):
+            one(n)
+        runs = 10 if first * 13 < budget else max(3, int(budget / max(first, 1e-3)) - warm)
+        ts = [one(n) for _ in range(runs)]
+        return statistics.median(ts), warm, runs
+
+    n_big = min(64, x.shape[0])
+    t1, w1, r1 = protocol(1, 0.2 * budget_s)
+    tb, wb, rb = protocol(n_big, 0.8 * budget_s)
+    return {'value': round(n_big / tb, 2), 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'host_cpu_count': os.cpu_count(),
+            'n1_latency_ms': round(1e3 * t1, 2), 'n1_images_per_sec': round(1.0 / t1, 2),
+            'sample': f'N={n_big}: median of {rb} runs after {wb} warm-ups ({tb:.2f} s per run); N=1: median of {r1} runs after {w1} '
+                      f'warm-ups; the same synthetic batch as the GPU run; torch-CPU fp32 restatement of the reference Keras model '
+                      f'+ C restatement of its NumPy decode/NMS (oracle/), not Keras itself'}
 
 
 def main():
@@ -65,188 +406,50 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step (configs[1]: 64)')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU-baseline sample: seconds of host work to time')
+    ap.add_argument('--mode', choices=['infer', 'train'], default='infer')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='inference arithmetic (configs[1] f32, configs[2] bf16)')
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU per step (default: 64 f32, 128 bf16, 32 train)')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the configs[2] / configs[3] measurements under "also"')
+    ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')
     ap.add_argument('--settle-ms', type=float, default=200.0, help='untimed steps after the warm-up until the clocks have settled')
-    ap.add_argument('--force-gather', action='store_true', help='developer check: run the N>1 code path (process group, detection gather) on one rank')
+    ap.add_argument('--force-gather', action='store_true',
+                    help='developer check: run the N>1 code path (process group, detection gather, all-reduce) on one rank')
     args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    multi = world > 1 or args.force_gather
-    if multi:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
-
-    from yolo_amd import ops, params as P
-    from yolo_amd.engine import DeviceModel
-
-    N, C = args.batch, 20
-    prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
-    model = DeviceModel(prm, C=C, device=dev)
-    x_cpu = torch.rand((N, 448, 448, 3), generator=torch.Generator(device='cpu').manual_seed(0))
-    x = x_cpu.to(dev)
-    ws = model.workspace(N)
-    gathered = None
-    if multi:
-        slots = 98
-        rec = torch.empty((N, slots, 6), dtype=torch.float64, device=dev)          # box(4) score cls*keep
-        gathered = torch.empty((world * N, slots, 6), dtype=torch.float64, device=dev)
-
-    def step():
-        boxes, score, cls, keep = model.detect(x)
-        if multi:                                      # detection gather: fixed-size records, one collective
-            ops.pack_detections(boxes, score, cls, keep, out=rec)
-            dist.all_gather_into_tensor(gathered, rec)
-        return keep
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if multi:
-            dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    # The shader clock of this chip climbs for tens of milliseconds after it leaves idle ("Clocks"): the
-    # same kernels run 10-12 % slower in the first few ms.  The metric is steady-state throughput, so untimed steps
-    # continue until the GPU has been busy for `--settle-ms` (default 200 ms) before anything is measured; the count is
-    # reported as `settle_steps`.  The timed region below is still exactly K steps.
-    settle_steps = 0
-    if multi:
-        # every rank must issue the same number of collectives: a fixed count (~1.6 ms per step), not a local clock
-        settle_steps = int(args.settle_ms / 1.6)
-        for _ in range(settle_steps):
-            step()
+    ctx = Ctx(args)
+    headline_is_default = args.mode == 'infer' and args.dtype == 'f32'
+    prm = x_cpu = None
+    if args.mode == 'train':
+        head = run_train(ctx, args, args.batch or 32)
+        metric = 'images/sec tiny-YOLOv1 448x448 training step (yolo_loss fwd/bwd, Dense wgrad, SUM all-reduce, Adam)'
     else:
-        t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_steps < 2000:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize(dev)
-            settle_steps += 10
-    sync_all()
-    # ---- survey pass (untimed): every library launch brackets itself with HIP events on its own stream; this gives
-    #      the per-kernel table and names the dominant kernel.  Bracketing EVERY launch costs ~5 % of a step, so the
-    #      timed region below keeps the brackets on the dominant kernel's launches only.
-    with ops.KernelTimer() as kt:
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        table = kt.table()
-    conv_names = {}
-    for k, v in table.items():
-        if k.startswith('conv') and v['ms'] > 0:
-            conv_names[k.split('@')[0]] = conv_names.get(k.split('@')[0], 0.0) + v['ms']
-    dom_prefix = max(conv_names, key=conv_names.get) + '@'
-    # ---- timed region: exactly K steps; the dominant kernel's launches are timed live with HIP events
-    with ops.KernelTimer(only=dom_prefix) as kt:
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            keep = step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        live = kt.table()
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kept_per_image = float(keep.sum().item()) / N
-
-    if rank == 0:
-        # un-instrumented repeat (no event records) to show what the instrumentation costs
-        sync_all() if world == 1 else None
-        plain = None
-        if world == 1:
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize(dev)
-            plain = time.perf_counter() - t1
-        # per-layer entries are named "<kernel>@<H>x<Cin>><Cout>"; the roofline object is quoted per kernel
-        # symbol (what rocprofv3 --stats aggregates), so fold the layers of one instantiation together
-        conv = {}
-        for k, v in table.items():
-            if k.startswith('conv') and v['ms'] > 0:
-                e = conv.setdefault(k.split('@')[0], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-                for f in e:
-                    e[f] += v[f]
-        dom_name = dom_prefix[:-1]
-        dom = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)        # the dominant kernel, timed inside the timed region
-        for k, v in live.items():
-            if k.startswith(dom_prefix):
-                for f in dom:
-                    dom[f] += v[f]
-        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-        kernels = {}
-        gpu_ms = sum(v['ms'] for v in table.values())
-        for k, v in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
-            kernels[k] = {'launches': v['launches'], 'avg_us': round(1e3 * v['ms'] / max(v['launches'], 1), 2),
-                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None,
-                          'algo_gbs': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None,
-                          'share': round(v['ms'] / gpu_ms, 3)}
-        conv_flops = sum(v['flops'] for k, v in table.items() if k.startswith(('conv', 'dense')))
-        conv_ms = sum(v['ms'] for k, v in table.items() if k.startswith(('conv', 'dense')))
-        # HBM traffic of the dominant kernel: measured in separate rocprofv3 --pmc passes of this same command
-        # (tools/profile.sh), committed under profiles/; averaged over that symbol's launches in one step
-        traffic, traffic_src = None, None
-        try:
-            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            sym = (ROCPROF_SYMBOL.get(dom_name) or '').replace('(anonymous namespace)::', '')
-            if sym in pj['kernels']:
-                traffic = round(pj['kernels'][sym]['hbm_read_bytes'] + pj['kernels'][sym]['hbm_write_bytes'])
-                traffic_src = pj['source']
-        except Exception:
-            pass
-        out = {
-            'metric': 'images/sec tiny-YOLOv1 448x448 inference incl. decode+NMS',
-            'value': round(world * N * args.steps / elapsed, 1),
-            'unit': 'images/sec',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'settle_steps': settle_steps,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: tiny-YOLOv1 448x448 batch={N}/GPU fp32 backbone+Dense+head+decode+NMS, '
-                                   'random-init weights (glorot, identity BN: dense-candidate NMS stress), '
-                                   'torch.rand images resident in HBM',
-                       'global_batch': world * N, 'per_gpu_batch': N,
-                       'sharding': 'batch split across ranks, no data-path collective'
-                                   + ('; all-gather of fixed-size detection records inside the step' if multi else ''),
-                       'kept_boxes_per_image': round(kept_per_image, 2)},
-            'roofline': {'bound': 'mfma', 'kernel': dom_name, 'rocprof_symbol': ROCPROF_SYMBOL.get(dom_name),
-                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
-                         'launches': dom['launches'], 'avg_launch_us': round(1e3 * dom['ms'] / dom['launches'], 2),
-                         'algo_flops_per_launch': dom['flops'] / dom['launches'],
-                         'all_matmul_kernels_tflops': round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                         'whole_step_frac_of_peak': round(
-                             (3.216e9 * world * N * args.steps / elapsed) / (world * PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
-            'kernels': kernels,
-            'kernels_note': 'per-kernel table from an untimed pass of the same K steps with every launch bracketed by HIP '
-                            'events; inside the timed region only the dominant kernel is bracketed (roofline.achieved)',
-        }
-        if plain is not None:
-            out['repeat_without_events_images_per_sec'] = round(N * args.steps / plain, 1)
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(prm, x_cpu, args.cpu_seconds, C)
-            cb['value'] = round(cb['value'], 2)
-            out['cpu_baseline'] = cb
+        head, prm, x_cpu = run_infer(ctx, args, args.dtype, args.batch or (64 if args.dtype == 'f32' else 128))
+        metric = 'images/sec tiny-YOLOv1 448x448 inference incl. decode+NMS'
+    out = {'metric': metric, 'value': head.pop('value'), 'unit': head.pop('unit'), 'n_gpus': ctx.world, 'steps': args.steps,
+           'warmup': args.warmup, 'settle_steps': head.pop('settle_steps'), 'ms_per_step': head.pop('ms_per_step'),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': head.pop('dtype'), 'data': 'synthetic'}
+    out.update(head)
+    if 'kernels' in out:
+        out['kernels_note'] = ('per-kernel table from an untimed pass of the same K steps with every launch bracketed by HIP '
+                               'events; inside the timed region only the dominant kernel is bracketed (roofline.achieved)')
+    if headline_is_default and not args.no_also:
+        also = {}
+        sub = argparse.Namespace(**vars(args))
+        sub.steps, sub.warmup, sub.settle_ms = min(args.steps, 50), min(args.warmup, 10), min(args.settle_ms, 100.0)
+        for key, fn in (('configs[2] bf16 inference', lambda: run_infer(ctx, sub, 'bf16', 128)[0]),
+                        ('configs[3] training step', lambda: run_train(ctx, sub, 32))):
+            torch.cuda.empty_cache()
+            r = fn()
+            r.pop('kernels', None)
+            r['steps'], r['warmup'] = sub.steps, sub.warmup
+            also[key] = r
+        out['also'] = also
+    if ctx.rank == 0:
+        if ctx.world == 1 and not args.no_cpu_baseline and prm is not None:
+            out['cpu_baseline'] = cpu_baseline(prm, x_cpu, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if multi:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == '__main__':

@@ -167,6 +167,47 @@ def test_training_step_vs_torch_reference_and_sharded_sum():
     assert losses[2] < losses[0]                                     # it learns
 
 
+def test_overlapped_step_equals_serial_step_one_rank_rccl():
+    """The step with its single all-reduce + Adam on a side stream, overlapped with the next batch's frozen backbone
+    (wait=False), gives the same bits as the serial step, over 3 steps, through RCCL (backend nccl) on one rank; and the
+    step issues exactly ONE collective carrying [dWt | db | loss]."""
+    import torch.distributed as dist
+    from test_parallel_gloo import _free_port
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        N = 4
+        prm = P.make_random_params(seed=6, dense_init='spread', bn='random')
+        xs = [torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(20 + i)).to(DEV) for i in range(3)]
+        ys = [torch.from_numpy(_labels(N, 20, 30 + i)).to(DEV) for i in range(3)]
+        calls = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(t.numel())
+            return real(t, *a, **k)
+        results = {}
+        for mode in ('serial', 'overlap'):
+            model = DeviceModel(prm, device=DEV)
+            tr = Trainer(model, overlap=(mode == 'overlap'))
+            assert tr.bucket.flat.numel() == 1472 * 12544 + 1470 + 1
+            tr.bucket.always = True          # a one-rank group would short-cut the collective: send it through RCCL
+            dist.all_reduce = counting
+            try:
+                losses = [tr.step(x, y, wait=(mode == 'serial')) for x, y in zip(xs, ys)]
+                tr.join()
+                torch.cuda.synchronize()
+            finally:
+                dist.all_reduce = real
+            results[mode] = (torch.cat(losses).cpu(), model.dense_wt.clone().cpu(), model.dense_b.clone().cpu(), tr.m.clone().cpu())
+        assert calls == [1472 * 12544 + 1470 + 1] * 6                    # one message per step, both modes
+        for a, b in zip(results['serial'], results['overlap']):
+            assert torch.equal(a, b)
+        assert results['serial'][0][2] < results['serial'][0][0] * 10     # finite, sane losses
+    finally:
+        dist.destroy_process_group()
+
+
 def test_keras_style_training_entry_points(tmp_path):
     outputs, inputs = model_tiny_YOLOv1()
     model = Model(inputs=inputs, outputs=outputs)

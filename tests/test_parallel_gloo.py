@@ -59,7 +59,27 @@ def _worker(rank, world, port, q):
         bounds = [(0, 5), (5, 8)]
         lo, hi = bounds[rank]
         dw, loss, y = _local_grads(y_true[lo:hi], feats[lo:hi], w)
-        parallel.allreduce_sum_([dw, loss])
+        # the training step's exchange: [dWt | db | loss] packed in one bucket = ONE collective (engine.Trainer uses
+        # this same class on the GPU); count the calls to prove it
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
+        bucket = parallel.GradBucket(1472, 64, 1470, 'cpu')
+        bucket.dwt[:1470].copy_(dw.t())
+        bucket.db.copy_(dw.sum(0))                       # any per-unit vector: the slot must travel and sum too
+        bucket.loss.copy_(loss)
+        db_local = bucket.db.clone()
+        work = bucket.allreduce(async_op=True)
+        work.wait()
+        dist.all_reduce = real
+        ok_one = calls == [1472 * 64 + 1470 + 1]
+        dw, loss = bucket.dwt[:1470].t().contiguous(), bucket.loss.clone()
+        other = [torch.zeros_like(db_local) for _ in range(world)]
+        dist.all_gather(other, db_local)
+        ok_one = ok_one and torch.allclose(bucket.db, other[0] + other[1]) and not bucket.dwt[1470:].any()
+        extra = [torch.ones(3) * (rank + 1)]
+        parallel.allreduce_sum_(extra)                   # the generic helper still sums without dividing
+        ok_one = ok_one and bool((extra[0] == 3).all())
         dw_full, loss_full, y_full = _local_grads(y_true, feats, w)
         ok_grad = torch.allclose(dw, dw_full, rtol=1e-4, atol=1e-6)
         ok_loss = abs(loss.item() - loss_full.item()) <= 1e-5 * abs(loss_full.item())
@@ -76,7 +96,7 @@ def _worker(rank, world, port, q):
         eq = parallel.gather_detections(rec[:3].contiguous())
         ok_eq = eq.shape[0] == 6
         spans = [parallel.shard_bounds(N, r, world) for r in range(world)]
-        q.put((rank, ok_grad, ok_loss, ok_det, ok_eq, spans == [(0, 4), (4, 8)]))
+        q.put((rank, ok_grad, ok_loss, ok_det, ok_eq, spans == [(0, 4), (4, 8)], ok_one))
     finally:
         dist.destroy_process_group()
 

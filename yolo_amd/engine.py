@@ -102,48 +102,103 @@ class Trainer:
     backbone and the Dense layer run forward, yolo_loss gives dL/dy_pred in closed form, the head
     Jacobian and the Dense weight gradient follow, gradients are all-reduced with SUM over the
     data-parallel group (the loss is a batch sum: SURVEY Q12, no division by world size), and Adam
-    (Keras defaults) updates the only trainable parameters: the Dense kernel and bias (Q8)."""
+    (Keras defaults) updates the only trainable parameters: the Dense kernel and bias (Q8).
 
-    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None):
+    Exchange and update are built to scale: [dWt | db | loss] is one flat buffer (parallel.GradBucket) = ONE all-reduce
+    per step, the parameters and Adam moments use the same [Wt | b] order = ONE Adam launch, and with overlap=True both
+    run on a side stream while the compute stream already runs the NEXT batch's backbone - legal because every conv
+    and BatchNormalization layer is frozen (/root/reference/models/model_tiny_yolov1.py:43-87, trainable=False), so
+    the backbone does not read anything the update writes.  The compute stream waits for the update only where it
+    needs the new Dense weights: in front of the next Dense forward (step(..., wait=False)), or at the end of the
+    step (wait=True, the default: the returned loss and the weights are then ordered on the caller's stream)."""
+
+    def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None, overlap=True):
         if model.dtype != 'f32':
             raise ValueError("training runs in fp32 (the reference's arithmetic): build the model with dtype='f32'")
+        from . import parallel
         self.model, self.group = model, group
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
-        dev = model.device
-        self.dwt = torch.zeros_like(model.dense_wt)
-        self.db = torch.zeros_like(model.dense_b)
-        self.m_w, self.v_w = torch.zeros_like(model.dense_wt), torch.zeros_like(model.dense_wt)
-        self.m_b, self.v_b = torch.zeros_like(model.dense_b), torch.zeros_like(model.dense_b)
+        dev = self.device = model.device
+        rows, ldk = model.dense_wt.shape
+        self.bucket = parallel.GradBucket(rows, ldk, model.units, dev)
+        self.dwt, self.db = self.bucket.dwt, self.bucket.db
+        # re-home the trainable parameters into one flat buffer in the bucket's order; the model keeps using views
+        n_w = rows * ldk
+        self.pflat = torch.empty(n_w + model.units, dtype=torch.float32, device=dev)
+        self.pflat[:n_w].view(rows, ldk).copy_(model.dense_wt)
+        self.pflat[n_w:].copy_(model.dense_b)
+        model.dense_wt, model.dense_b = self.pflat[:n_w].view(rows, ldk), self.pflat[n_w:]
+        self.m, self.v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
         self.t = 0
         self.ldz = ops.round_up(model.units, 4)
         self._dz = {}
-        self.device = dev
+        self.side = torch.cuda.Stream(dev) if overlap else None
+        self._grads_ready = torch.cuda.Event()
+        self._updated = torch.cuda.Event()
+        self._pending = False            # an update is in flight on the side stream
+        self.collective_events = None    # (start, end) CUDA events around the last all-reduce when time_collective is set
+        self.time_collective = False
+        self.skip_collective = False     # measurement only (bench: step time without the exchange)
 
     def gradients(self, x, y_true):
         """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
         return self.gradients_from_features(self.model.backbone(x, self.model.workspace(x.shape[0])), y_true)
 
     def gradients_from_features(self, feats, y_true):
-        """The trainable part of the step (Dense -> head -> yolo_loss and back) on frozen-backbone features (N, K)."""
+        """The trainable part of the step (Dense -> head -> yolo_loss and back) on frozen-backbone features (N, K).
+        Writes dWt, db and the local loss into the bucket; returns the bucket's loss slot."""
         m = self.model
         N = feats.shape[0]
         ws = m.workspace(N)
         y = m.head(feats, ws)
-        loss, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size)
+        _, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size, loss_out=self.bucket.loss)
         dz = self._dz.get(N)
         if dz is None:
             dz = self._dz[N] = torch.empty((N, self.ldz), dtype=torch.float32, device=self.device)
         ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
         ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
+        return self.bucket.loss
+
+    def join(self):
+        """Make the current stream wait for the update in flight on the side stream (no host synchronisation)."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_event(self._updated)
+            self._pending = False
+
+    def _exchange_and_update(self):
+        """ONE all-reduce of the bucket, the global loss copied out, ONE Adam launch - on the current stream."""
+        if not self.skip_collective:
+            if self.time_collective:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            work = self.bucket.allreduce(self.group, async_op=True)
+            if work is not None:
+                work.wait()                      # stream-ordered wait on the collective's stream, not a host wait
+            if self.time_collective:
+                e1.record()
+                self.collective_events = (e0, e1)
+        loss = self.bucket.loss.clone()
+        self.t += 1
+        ops.adam_step(self.pflat, self.bucket.grads, self.m, self.v, self.t, self.lr, self.beta1, self.beta2, self.eps)
         return loss
 
-    def step(self, x, y_true):
-        """x (n,448,448,3), y_true (n,S,S,C+5) on the device -> global batch loss (1,) on the device."""
-        from . import parallel
-        loss = self.gradients(x, y_true)
-        parallel.allreduce_sum_([self.dwt, self.db, loss], self.group)
-        self.t += 1
-        m = self.model
-        ops.adam_step(m.dense_wt, self.dwt, self.m_w, self.v_w, self.t, self.lr, self.beta1, self.beta2, self.eps)
-        ops.adam_step(m.dense_b, self.db, self.m_b, self.v_b, self.t, self.lr, self.beta1, self.beta2, self.eps)
+    def step(self, x, y_true, wait=True):
+        """x (n,448,448,3), y_true (n,S,S,C+5) on the device -> global batch loss (1,) on the device.
+        wait=False leaves the exchange + update in flight on the side stream (the next step() or join() waits for it
+        in front of its Dense forward); the returned loss is then valid only after join() / a device synchronise."""
+        feats = self.model.backbone(x, self.model.workspace(x.shape[0]))     # frozen: overlaps the update in flight
+        self.join()
+        self.gradients_from_features(feats, y_true)
+        if self.side is None:
+            return self._exchange_and_update()
+        cur = torch.cuda.current_stream(self.device)
+        self._grads_ready.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self._grads_ready)
+            loss = self._exchange_and_update()
+            self._updated.record(self.side)
+        loss.record_stream(cur)
+        self._pending = True
+        if wait:
+            self.join()
         return loss

@@ -281,15 +281,16 @@ def iou_f64(pred_mins, pred_maxes, true_mins, true_maxes):
     return out
 
 
-def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True):
-    """-> loss (1,) f32 batch SUM, loss_per_image (N,), grad (N,S,S,C+5B) or None."""
+def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True, loss_out=None):
+    """-> loss (1,) f32 batch SUM, loss_per_image (N,), grad (N,S,S,C+5B) or None.
+    loss_out: optional (1,) f32 device tensor the batch loss is written to (e.g. a slot of the gradient bucket)."""
     _chk(y_true, torch.float32, 'y_true'); _chk(y_pred, torch.float32, 'y_pred')
     N, S = y_pred.shape[0], y_pred.shape[1]
     if tuple(y_true.shape) != (N, S, S, C + 5) or tuple(y_pred.shape) != (N, S, S, C + 5 * B):
         raise ValueError(f'shapes {tuple(y_true.shape)} / {tuple(y_pred.shape)} do not match B={B}, C={C}')
     dev = y_pred.device
     per = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
-    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev) if loss_out is None else _chk_out(loss_out, torch.float32, (1,), 'loss_out')
     grad = torch.empty_like(y_pred) if want_grad else None
     _lib.call('ty1_yolo_loss_fwd_bwd', y_true.data_ptr(), y_pred.data_ptr(), N, S, B, C, int(img_size),
               per.data_ptr(), loss.data_ptr(), _lib.ptr(grad), _lib.current_stream())
