@@ -177,7 +177,10 @@ def test_overlapped_step_equals_serial_step_one_rank_rccl():
                             device_id=torch.device(DEV))
     try:
         N = 4
-        prm = P.make_random_params(seed=6, dense_init='spread', bn='random')
+        # (glorot Dense weights and a small learning rate: with features of RMS ~7 one Adam step at lr 1e-3 moves a logit by
+        #  tens of units; below -104 a sigmoid is exactly 0 in fp32, and for a box width of exactly 0 the reference's
+        #  autodiff - and therefore ty1_yolo_loss_fwd_bwd - gives NaN for d sqrt(w) / dw)
+        prm = P.make_random_params(seed=6, dense_init='glorot', bn='random')
         xs = [torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(20 + i)).to(DEV) for i in range(3)]
         ys = [torch.from_numpy(_labels(N, 20, 30 + i)).to(DEV) for i in range(3)]
         calls = []
@@ -189,7 +192,7 @@ def test_overlapped_step_equals_serial_step_one_rank_rccl():
         results = {}
         for mode in ('serial', 'overlap'):
             model = DeviceModel(prm, device=DEV)
-            tr = Trainer(model, overlap=(mode == 'overlap'))
+            tr = Trainer(model, lr=1e-5, overlap=(mode == 'overlap'))
             assert tr.bucket.flat.numel() == 1472 * 12544 + 1470 + 1
             tr.bucket.always = True          # a one-rank group would short-cut the collective: send it through RCCL
             dist.all_reduce = counting
@@ -202,8 +205,8 @@ def test_overlapped_step_equals_serial_step_one_rank_rccl():
             results[mode] = (torch.cat(losses).cpu(), model.dense_wt.clone().cpu(), model.dense_b.clone().cpu(), tr.m.clone().cpu())
         assert calls == [1472 * 12544 + 1470 + 1] * 6                    # one message per step, both modes
         for a, b in zip(results['serial'], results['overlap']):
-            assert torch.equal(a, b)
-        assert results['serial'][0][2] < results['serial'][0][0] * 10     # finite, sane losses
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+        assert results['serial'][0][2] < results['serial'][0][0]          # it learns
     finally:
         dist.destroy_process_group()
 

@@ -9,7 +9,14 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Both branches keep exp() finite: 1 / (1 + exp(-v)) alone returns exactly 0 from v < -88.7 on (exp overflows), while the
+// true value stays a positive fp32 number down to v = -103.9 - and a box width of exactly 0 is where yolo_loss' sqrt has
+// no finite derivative (csrc/loss.hip: dwh).
+__device__ __forceinline__ float sigmoidf_(float v) {
+    if (v >= 0.f) return 1.0f / (1.0f + expf(-v));
+    const float e = expf(v);
+    return e / (1.0f + e);
+}
 
 // grid (N, ceil(cells / kCellsPerBlock)): a block owns a few cells of one image, so even a small batch
 // spreads over the chip and the split-K reduction (tens of partial slabs) runs as independent loads.
