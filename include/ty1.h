@@ -70,6 +70,22 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
                                 void *workspace, size_t workspace_bytes, ty1_stream_t stream);
 
 /*
+ * The same block for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same kernels and same results as
+ * ty1_conv3x3_bn_leaky_ws_f32 given a workspace of ty1_conv3x3_workspace_bytes(), but the scratch for the K-split tail
+ * is a 16 MiB array inside the library's code object (one copy per GPU, held until the process ends): the call makes
+ * no hipMalloc / hipFree and needs no workspace argument.  A problem whose tail wants more than
+ * ty1_static_scratch_bytes() (16 MiB; batch 64 of every layer of the network fits) is rejected with an error - use the
+ * _ws_ entry point for it.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams,
+ * two threads) race; calls on one stream are ordered.  Nothing in the array has to be zero: every byte that is read was
+ * written by the same call.
+ */
+size_t ty1_static_scratch_bytes(void);
+int ty1_conv3x3_bn_leaky_static_f32(const float *x, const float *w, const float *scale, const float *shift,
+                                    float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                                    ty1_stream_t stream);
+
+/*
  * The same block for the bf16 network (BASELINE config "batch=1024 bf16 inference", 128 images per GPU):
  * activations and weights in bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, folded BN + LeakyReLU + pool
  * in fp32, output rounded to bf16 (nearest even).  Same reference lines as above

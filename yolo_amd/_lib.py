@@ -16,6 +16,8 @@ SIGNATURES = {
     'ty1_conv3x3_bn_leaky_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     'ty1_conv3x3_workspace_bytes': [_i, _i, _i, _i, _i, _i, _vp],
     'ty1_conv3x3_bn_leaky_ws_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _c.c_size_t, _vp],
+    'ty1_conv3x3_bn_leaky_static_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    'ty1_static_scratch_bytes': [],
     'ty1_conv3x3_workspace_bytes_bf16': [_i, _i, _i, _i, _i, _i, _vp],
     'ty1_conv3x3_bn_leaky_bf16': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _c.c_size_t, _vp],
     'ty1_cast_f32_to_bf16': [_vp, _vp, _i64, _vp],
@@ -60,7 +62,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = _i
+            fn.restype = _c.c_size_t if name == 'ty1_static_scratch_bytes' else _i
         L.ty1_last_error.restype = _c.c_char_p
         L.ty1_last_error.argtypes = []
         _LIB = L

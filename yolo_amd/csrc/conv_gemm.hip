@@ -29,6 +29,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+
+#ifndef TY1_STATIC_SCRATCH_BYTES
+#define TY1_STATIC_SCRATCH_BYTES (16u << 20)      // ty1_conv3x3_bn_leaky_static_f32: 16 MiB per GPU
+#endif
 
 namespace {
 
@@ -1151,6 +1156,57 @@ extern "C" int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const
                                            float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
                                            void *workspace, size_t workspace_bytes, ty1_stream_t stream) {
     return conv3x3_dispatch(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, (float *)workspace, workspace_bytes,
+                            nullptr, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Entry point that allocates nothing (include/ty1.h: ty1_conv3x3_bn_leaky_static_f32).  The partial tiles of the K-split
+// tail go to a scratch array that is part of this code object: every GPU the library runs on holds its own copy until
+// the process ends.  In host code the array's name is only a handle; its device address on the current GPU comes from
+// hipGetSymbolAddress, once per device, and only that pointer is ever passed to a kernel.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kStaticScratchBytes = TY1_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+void *g_scratch_ptr[64] = {};          // device address of `scratch`, per device id
+std::mutex g_scratch_mutex;
+
+int static_scratch_ptr(void **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return ty1::fail("ty1_conv3x3_bn_leaky_static_f32: hipGetDevice failed: %s", hipGetErrorString(e));
+    TY1_REQUIRE(dev >= 0 && dev < 64, "ty1_conv3x3_bn_leaky_static_f32: device id %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return ty1::fail("ty1_conv3x3_bn_leaky_static_f32: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                             hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t ty1_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int ty1_conv3x3_bn_leaky_static_f32(const float *x, const float *w, const float *scale, const float *shift,
+                                               float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
+                                               ty1_stream_t stream) {
+    size_t need = 0;
+    if (int rc = conv3x3_dispatch(nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, pool, 0.f, nullptr, 0, &need, nullptr))
+        return rc;
+    TY1_REQUIRE(need <= kStaticScratchBytes,
+                "ty1_conv3x3_bn_leaky_static_f32: this problem (N=%d %dx%d %d->%d) wants %zu bytes of scratch for its K-split tail, "
+                "the static buffer holds %zu: pass a workspace to ty1_conv3x3_bn_leaky_ws_f32 instead",
+                N, H, W, Cin, Cout, need, kStaticScratchBytes);
+    void *ptr = nullptr;
+    if (need) {
+        if (int rc = static_scratch_ptr(&ptr)) return rc;
+    }
+    return conv3x3_dispatch(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, (float *)ptr, need ? kStaticScratchBytes : 0,
                             nullptr, (hipStream_t)stream);
 }
 

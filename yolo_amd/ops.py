@@ -74,6 +74,24 @@ def conv3x3_bn_leaky(x, w_ohwi, scale, shift, pool, alpha=0.1, out=None, workspa
     return out
 
 
+def static_scratch_bytes():
+    return int(_lib.lib().ty1_static_scratch_bytes())
+
+
+def conv3x3_bn_leaky_static(x, w_ohwi, scale, shift, pool, alpha, out):
+    """The conv block through the entry point that allocates nothing (ty1_conv3x3_bn_leaky_static_f32): the caller
+    brings every buffer, the K-split scratch is the library's static device array."""
+    _chk(x, torch.float32, 'x'); _chk(w_ohwi, torch.float32, 'w')
+    _chk(scale, torch.float32, 'scale'); _chk(shift, torch.float32, 'shift')
+    N, H, W, Cin = x.shape
+    Cout = w_ohwi.shape[0]
+    assert tuple(w_ohwi.shape) == (Cout, 3, 3, Cin), w_ohwi.shape
+    _chk_out(out, torch.float32, (N, H // 2, W // 2, Cout) if pool else (N, H, W, Cout), 'out')
+    _lib.call('ty1_conv3x3_bn_leaky_static_f32', x.data_ptr(), w_ohwi.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              out.data_ptr(), N, H, W, Cin, Cout, int(bool(pool)), float(alpha), _lib.current_stream())
+    return out
+
+
 def conv3x3_workspace_bytes_bf16(N, H, W, Cin, Cout, pool):
     """Scratch bytes ty1_conv3x3_bn_leaky_bf16 wants for this problem."""
     import ctypes
