@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/ty1.h"
@@ -30,6 +31,14 @@ inline int check_launch(const char *what) {
     if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
     return 0;
 }
+
+// Developer overrides (TY1_TILE, TY1_DBG, TY1_NO_TAIL_SPLIT ...) exist in the dev build only (tools/build_dev.sh,
+// -DTY1_DEV_STAMPS -> libty1_dev.so): the shipping library reads no environment variable.
+#ifdef TY1_DEV_STAMPS
+inline const char *dev_env(const char *name) { return getenv(name); }
+#else
+inline const char *dev_env(const char *) { return nullptr; }
+#endif
 
 // developer timeline buffer (8 x i64 per workgroup), set by ty1_debug_stamp_buffer; see tools/stamp_trace.py
 extern long long *g_stamp;

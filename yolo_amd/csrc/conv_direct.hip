@@ -698,9 +698,9 @@ template <typename K>
 int resident_blocks(K kernel, int cap, const char *env) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
-    if (const char *e = getenv(env)) occ = atoi(e) > 0 ? atoi(e) : occ;
+    if (const char *e = ty1::dev_env(env)) occ = atoi(e) > 0 ? atoi(e) : occ;
     else if (occ > cap) occ = cap;
-    if (getenv("TY1_VERBOSE")) fprintf(stderr, "[ty1] %s: %d resident workgroups per CU\n", env, occ);
+    if (ty1::dev_env("TY1_VERBOSE")) fprintf(stderr, "[ty1] %s: %d resident workgroups per CU\n", env, occ);
     return occ;
 }
 }  // namespace

@@ -885,14 +885,14 @@ struct TailPlan {
 };
 TailPlan plan_tail(int T, int C, int slots) {
     TailPlan p{T, 0, 1};
-    static const char *off = getenv("TY1_NO_TAIL_SPLIT");
+    static const char *off = ty1::dev_env("TY1_NO_TAIL_SPLIT");
     if (off || T % slots == 0 || C < 2) return p;
     // (measured with per-CU end-time stamps, 7x7x512->1024 at batch 64: 96 pieces left 160 CUs idle for the last 5 % of the
     //  kernel; the piece count that gives every CU the same share wins even though it is the largest split)
     const double ovh = 3.0, fix = 4.0, fix_per_split = 0.1;
     double best = std::ceil((double)T / slots) * (C + ovh);
     const int rem = T % slots, whole = T - rem;
-    static const char *hyst = getenv("TY1_TAIL_HYST");        // developer override: required gain per step (default 0.5 %)
+    static const char *hyst = ty1::dev_env("TY1_TAIL_HYST");        // developer override: required gain per step (default 0.5 %)
     const double need = hyst ? atof(hyst) : 0.995;
     for (int s = 2; s <= 32 && C / s >= 3; ++s) {        // a piece keeps >= 3 chunks (fetch cursor of the persistent kernel)
         const int per = (C + s - 1) / s;
@@ -940,7 +940,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     // persistent grid: as many workgroups as stay resident together (LDS / register limited), at least 2 per CU
     static const int occ = [] {
         int n = 0;
-        static const char *cap = getenv("TY1_MAX_BLOCKS_PER_CU");
+        static const char *cap = ty1::dev_env("TY1_MAX_BLOCKS_PER_CU");
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL, OP, OUT_BF16>,
                                                          64 * WAVES_M * WAVES_N, 0) != hipSuccess || n < 1)
             n = 2;
@@ -949,7 +949,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
     }();
     const int grid = items < occ * num_cus() ? items : occ * num_cus();
     a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
-    static const char *dbg = getenv("TY1_DBG");
+    static const char *dbg = ty1::dev_env("TY1_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
     // algorithmic work: 2*M*N*K flops; input + weights read once, output written once
     const double K = 9.0 * c.Cin, out_rows = POOL ? c.M / 4.0 : (double)c.M;
@@ -997,7 +997,7 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
         const double px = (double)N * H * W;
         ty1::ProfScope prof(pool ? "conv3x3_c3_pool" : "conv3x3_c3", s, 2.0 * px * Cout * 27,
                             4.0 * (px * 3 + 27.0 * Cout + px * Cout / (pool ? 4 : 1)));
-        static const char *old_c3 = getenv("TY1_OLD_C3");             // developer override
+        static const char *old_c3 = ty1::dev_env("TY1_OLD_C3");             // developer override
         // (the persistent kernel pools before it activates, which needs a non-decreasing LeakyReLU: alpha >= 0)
         if (W % 4 == 0 && ((uintptr_t)x & 15) == 0 && alpha >= 0.f && !old_c3)
             return ty1::conv3x3_c3_persistent(x, w, scale, shift, y, N, H, W, Cout, pool, alpha, 0, s);
@@ -1021,7 +1021,7 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     a.alpha = alpha;
     const bool p = pool != 0;
 
-    static const char *no_direct = getenv("TY1_NO_DIRECT16");          // developer override
+    static const char *no_direct = ty1::dev_env("TY1_NO_DIRECT16");          // developer override
     // shallow K: direct kernel, weights in registers (it pools before it activates: needs alpha >= 0; one image < 2 GiB)
     if (Cin == 16 && (Cout == 32 || Cout == 64) && alpha >= 0.f && (long long)H * W * 64 < (1ll << 31) && !no_direct) {
         if (ws_need) return 0;
@@ -1034,7 +1034,7 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
         return ty1::fail("ty1_conv3x3: Cin=%d needs Cout %% 32 == 0 (got %d)", Cin, Cout);
     }
     const long long mt128 = ((long long)a.M + 127) / 128;
-    static const char *force = getenv("TY1_TILE");          // developer override
+    static const char *force = ty1::dev_env("TY1_TILE");          // developer override
     if (force && !strcmp(force, "128x128") && Cout % 128 == 0) return run_conv_p<2, 2, 2, 2, 32>("128x128", p, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "128x64") && Cout % 64 == 0) return run_conv_p<2, 1, 2, 2, 32>("128x64", p, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "64x64") && Cout % 64 == 0) return run_conv_p<1, 1, 2, 2, 32>("64x64", p, a, ws, ws_bytes, ws_need, s);
