@@ -15,6 +15,7 @@ ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--layers', default='0,1,2,3,4,5,6,7')
 ap.add_argument('--prof', action='store_true', help='also print the per-kernel HIP-event table')
 ap.add_argument('--no-ws', action='store_true', help='run without the tail-split workspace')
+ap.add_argument('--bf16', action='store_true', help='the bf16 network layers (ty1_conv3x3_bn_leaky_bf16)')
 ap.add_argument('--shapes', default='', help='extra cases "N,H,cin,cout,pool;..."')
 args = ap.parse_args()
 dev = 'cuda:0'
@@ -28,14 +29,21 @@ for i, (cin, cout) in enumerate(P.CONV_CHANNELS):
         x = torch.rand((args.batch, h, h, cin), device=dev)
         w = torch.randn((cout, 3, 3, cin), device=dev) * 0.05
         sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-        ws = None if args.no_ws else torch.empty(max(16, ops.conv3x3_workspace_bytes(args.batch, h, h, cin, cout, pool)), dtype=torch.uint8, device=dev)
-        out = ops.conv3x3_bn_leaky(x, w, sc, sh, pool, workspace=ws)
+        if args.bf16:
+            if cin != 3:
+                x, w = x.to(torch.bfloat16), w.to(torch.bfloat16)
+            ws = None if args.no_ws else torch.empty(max(16, ops.conv3x3_workspace_bytes_bf16(args.batch, h, h, cin, cout, pool)), dtype=torch.uint8, device=dev)
+            run = lambda out=None: ops.conv3x3_bn_leaky_bf16(x, w, sc, sh, pool, out_f32=(i == 7), out=out, workspace=ws)
+        else:
+            ws = None if args.no_ws else torch.empty(max(16, ops.conv3x3_workspace_bytes(args.batch, h, h, cin, cout, pool)), dtype=torch.uint8, device=dev)
+            run = lambda out=None: ops.conv3x3_bn_leaky(x, w, sc, sh, pool, out=out, workspace=ws)
+        out = run()
         for _ in range(3):
-            ops.conv3x3_bn_leaky(x, w, sc, sh, pool, out=out, workspace=ws)
+            run(out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ops.conv3x3_bn_leaky(x, w, sc, sh, pool, out=out, workspace=ws)
+            run(out)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / args.iters

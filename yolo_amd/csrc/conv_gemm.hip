@@ -1043,6 +1043,11 @@ int conv3x3_dispatch(const float *x, const float *w, const float *scale, const f
     if (Cout % 64 == 0) {
         if (mt128 * (Cout / 64) >= 2 * num_cus() || a.M >= 4096 * 2)
             return run_conv_p<2, 1, 2, 2, 32>("128x64", p, a, ws, ws_bytes, ws_need, s);
+        // too few 64x64 tiles to give every CU one (7x7x1024->256 at batch 64: 196): the layer is all K-split tail either
+        // way, and large tiles fetch half the bytes per MFMA (measured 127 -> 121 us; at M < 2048 the small tile still wins)
+        const long long mt64 = ((long long)a.M + 63) / 64;
+        if (Cout % 128 == 0 && Cin >= 512 && mt64 * (Cout / 64) < num_cus() && a.M >= 2048)
+            return run_conv_p<2, 2, 2, 2, 32>("128x128", p, a, ws, ws_bytes, ws_need, s);
         return run_conv_p<1, 1, 2, 2, 32>("64x64", p, a, ws, ws_bytes, ws_need, s);
     }
     if (Cout % 32 == 0) return run_conv_p<2, 1, 4, 1, 32>("256x32", p, a, ws, ws_bytes, ws_need, s);
@@ -1106,7 +1111,14 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
         return run_conv_bf16<2, 1, 2, 2, 16>("bk16_128x64", p, of, a, ws, ws_bytes, ws_need, s);
     }
     const long long mt128 = ((long long)a.M + 127) / 128;
-    if (Cout % 128 == 0 && mt128 * (Cout / 128) >= 2 * num_cus())
+    static const char *force = ty1::dev_env("TY1_TILE");          // developer override
+    if (force && !strcmp(force, "128x128") && Cout % 128 == 0) return run_conv_bf16<2, 2, 2, 2, 32>("128x128", p, of, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "128x64") && Cout % 64 == 0) return run_conv_bf16<2, 1, 2, 2, 32>("128x64", p, of, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "64x64") && Cout % 64 == 0) return run_conv_bf16<1, 1, 2, 2, 32>("64x64", p, of, a, ws, ws_bytes, ws_need, s);
+    // 128x128 once it fills the chip, and also when even 128x64 tiles would not give two rounds (7x7x1024->256 at 128 images:
+    // 196 tiles): such a layer is K-split either way and the bf16 kernel is bound by fetched bytes per MFMA, which the large
+    // tile halves (measured 103 -> 50 us against the 64x64 tile, 71 us with 128x64)
+    if (Cout % 128 == 0 && (mt128 * (Cout / 128) >= 2 * num_cus() || (Cin >= 512 && mt128 * (Cout / 64) < 2 * num_cus())))
         return run_conv_bf16<2, 2, 2, 2, 32>("128x128", p, of, a, ws, ws_bytes, ws_need, s);
     TY1_REQUIRE(Cout % 64 == 0, "ty1_conv3x3_bf16: Cout=%d must be a multiple of 64 when Cin >= 32", Cout);
     if (mt128 * (Cout / 64) >= 2 * num_cus() || a.M >= 4096 * 2)
