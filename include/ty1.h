@@ -159,6 +159,16 @@ int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int img_size, 
                    double *boxes, float *score, int32_t *cls, uint8_t *keep, ty1_stream_t stream);
 
 /*
+ * The inference tail behind the Dense GEMM in one launch: ty1_head_activate_f32 followed by ty1_decode_nms, same
+ * arithmetic and same results bit for bit (one workgroup per image reduces and activates the logits into LDS, its first
+ * wavefront decodes them).  Replaces /root/reference/models/model_tiny_yolov1.py:14-34 and
+ * /root/reference/tiny_yolov1.py:82-140 together.  y (N,S,S,C+5B) may be NULL: the head tensor then never reaches HBM.
+ */
+int ty1_head_decode_nms_f32(const float *part, const float *bias, float *y, int N, int S, int B, int C, int ldz,
+                            int splits, int img_size, double iou_thr, double *boxes, float *score, int32_t *cls,
+                            uint8_t *keep, ty1_stream_t stream);
+
+/*
  * Wire format after the path: fixed-size records for the multi-GPU detection gather.
  * The reference has no counterpart beyond drawing the kept boxes (/root/reference/tiny_yolov1.py:142-160);
  * the record keeps exactly what that loop reads: corners, confidence, class.

@@ -191,6 +191,31 @@ def test_head_activate_vs_reference_goldens(name, C):
     np.testing.assert_allclose(y3[moderate], want[moderate], rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,C,splits', [(1, 20, 3), (16, 20, 8), (64, 20, 5), (33, 1, 1)])
+def test_fused_head_decode_nms_equals_the_two_launches(N, C, splits):
+    """ty1_head_decode_nms_f32 (the inference tail in one launch) against ty1_head_activate_f32 + ty1_decode_nms: the
+    same arithmetic, so every output - head tensor, boxes, scores, classes, keep - must agree bit for bit; and against
+    the oracle on the same logits."""
+    rng = np.random.default_rng(100 + N)
+    units = 49 * (C + 10)
+    ldz = ops.round_up(units, 4)
+    part = np.zeros((splits, N, ldz), np.float32)
+    part[:, :, :units] = (2.0 * rng.standard_normal((splits, N, units)) / np.sqrt(splits)).astype(np.float32)
+    bias = rng.standard_normal(units).astype(np.float32)
+    pd, bd = dev(part), dev(bias)
+    y2 = ops.head_activate(pd, bd, 7, 2, C)
+    want = ops.decode_nms(y2, 2, C, 448)
+    y1 = torch.full_like(y2, float('nan'))
+    got = ops.head_decode_nms(pd, bd, 7, 2, C, 448, 0.2, y=y1)
+    assert torch.equal(y1, y2)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    got_noy = ops.head_decode_nms(pd, bd, 7, 2, C, 448, 0.2)               # head tensor kept in LDS only
+    assert all(torch.equal(a, b) for a, b in zip(got_noy, want))
+    assert_detections_equal(got, oracle.decode_nms(y2.cpu().numpy(), 2, C, 448))
+    z = part.sum(0)[:, :units] + bias
+    np.testing.assert_allclose(y1.cpu().numpy(), model_ref.head_activate_ref(z, 7, 2, C), rtol=1e-3, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------- whole model
 @pytest.mark.parametrize('N,C,bn', [(2, 20, 'random'), (1, 1, 'identity')])
 def test_model_end_to_end_vs_oracle(N, C, bn):

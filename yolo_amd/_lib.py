@@ -26,6 +26,7 @@ SIGNATURES = {
     'ty1_dense_splitk_bf16': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_head_activate_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_decode_nms': [_vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
+    'ty1_head_decode_nms_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp],
     'ty1_pack_detections': [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'ty1_yolo_head_np_f64': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'ty1_iou_f64': [_vp, _vp, _vp, _vp, _vp, _i64, _vp],

@@ -13,6 +13,7 @@
 // Strict IEEE arithmetic is required for bit-exact parity: this file is compiled with
 // -ffp-contract=off and uses no fast-math.
 #include "common.h"
+#include "head_math.h"
 
 #pragma clang fp contract(off)
 
@@ -91,31 +92,12 @@ __device__ __forceinline__ double iou_f64(const double amin[2], const double ama
     return inter / uni;
 }
 
+// One wavefront, one image: `img` is the image's head tensor (S,S,C+5B) in LDS; lane = grid cell.
 template <int B>
-__global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict__ pred, int N, int S, int C,
-                                                          int img_size, double iou_thr, int img_stride, int vec2,
-                                                          double *__restrict__ boxes, float *__restrict__ score,
-                                                          int32_t *__restrict__ cls, uint8_t *__restrict__ keep) {
-    extern __shared__ float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + wave;
-    const bool active = n < N;
-    const int cells = S * S, D = C + 5 * B, slots = cells * B, total = cells * D;
-    float *img = lds + wave * img_stride;
-
-    if (active) {
-        const float *src = pred + (size_t)n * total;
-        // 8-byte loads when every image base is 8-byte aligned (checked on the host)
-        if (vec2) {
-            const float2 *s2 = reinterpret_cast<const float2 *>(src);
-            float2 *d2 = reinterpret_cast<float2 *>(img);
-            for (int i = lane; i < total / 2; i += 64) d2[i] = s2[i];
-        } else {
-            for (int i = lane; i < total; i += 64) img[i] = src[i];
-        }
-    }
-    __syncthreads();
-
+__device__ __forceinline__ void decode_nms_wave(const float *img, int n, bool active, int lane, int S, int C, int img_size,
+                                                double iou_thr, double *__restrict__ boxes, float *__restrict__ score,
+                                                int32_t *__restrict__ cls, uint8_t *__restrict__ keep) {
+    const int cells = S * S, D = C + 5 * B, slots = cells * B;
     const bool valid = active && lane < cells;
     const float *pc = img + (valid ? lane : 0) * D;
     const float NEG_INF = -__builtin_inff();
@@ -231,6 +213,75 @@ __global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict
     }
 }
 
+template <int B>
+__global__ __launch_bounds__(256) void decode_nms_kernel(const float *__restrict__ pred, int N, int S, int C,
+                                                          int img_size, double iou_thr, int img_stride, int vec2,
+                                                          double *__restrict__ boxes, float *__restrict__ score,
+                                                          int32_t *__restrict__ cls, uint8_t *__restrict__ keep) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    const bool active = n < N;
+    const int total = S * S * (C + 5 * B);
+    float *img = lds + wave * img_stride;
+
+    if (active) {
+        const float *src = pred + (size_t)n * total;
+        // 8-byte loads when every image base is 8-byte aligned (checked on the host)
+        if (vec2) {
+            const float2 *s2 = reinterpret_cast<const float2 *>(src);
+            float2 *d2 = reinterpret_cast<float2 *>(img);
+            for (int i = lane; i < total / 2; i += 64) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += 64) img[i] = src[i];
+        }
+    }
+    __syncthreads();
+    decode_nms_wave<B>(img, n, active, lane, S, C, img_size, iou_thr, boxes, score, cls, keep);
+}
+
+// The whole inference tail behind the Dense GEMM in ONE launch: split-K reduction + bias, ReshapeYOLO.call, decode,
+// adaptive threshold, NMS.  One 1024-thread workgroup per image: all sixteen waves reduce and activate the image's
+// S*S*(C+5B) logits into LDS (the arithmetic of ty1_head_activate_f32: head_math.h), then wave 0 runs the decode + NMS
+// of ty1_decode_nms on that LDS image.  The head tensor goes to HBM only if the caller asks for it (y != nullptr).
+constexpr int kTailThreads = 1024;
+template <int B>
+__global__ __launch_bounds__(kTailThreads) void head_decode_nms_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                               float *__restrict__ y, int N, int S, int C, int ldz, int splits,
+                                                               int img_size, double iou_thr, double *__restrict__ boxes,
+                                                               float *__restrict__ score, int32_t *__restrict__ cls,
+                                                               uint8_t *__restrict__ keep) {
+    extern __shared__ float lds[];
+    const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
+    float *z = lds, *img = lds + ((units + 1) & ~1), *smx = img + ((units + 1) & ~1), *ssum = smx + 64;
+    const size_t slab = (size_t)N * ldz;
+    const float *pn = part + (size_t)n * ldz;
+    for (int t = threadIdx.x; t < units; t += kTailThreads) {
+        const int cell = t / D, d = t - cell * D;
+        z[t] = ty1::reduce_unit(pn, slab, ty1::planar_unit(cell, d, cells, B, C), bias, splits);
+    }
+    __syncthreads();
+    // softmax maximum and denominator once per cell, in activate_channel's order (same bits), instead of once per channel
+    if ((int)threadIdx.x < cells) {
+        const float *zc = z + threadIdx.x * D;
+        float mx = zc[0];
+        for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
+        float sum = 0.f;
+        for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
+        smx[threadIdx.x] = mx;
+        ssum[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < units; t += kTailThreads) {
+        const int cell = t / D, d = t - cell * D;
+        const float v = d < C ? expf(z[t] - smx[cell]) / ssum[cell] : ty1::sigmoid_f32(z[t]);
+        img[t] = v;
+        if (y) y[(size_t)n * units + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) decode_nms_wave<B>(img, n, true, (int)threadIdx.x, S, C, img_size, iou_thr, boxes, score, cls, keep);
+}
+
 // NumPy twins of the reference (tiny_yolov1.py:36-72): YOLO_head with xy in float64 and wh in float32,
 // iou in float64.  feats has no batch axis there; a leading batch axis is accepted here.
 __global__ void yolo_head_np_kernel(const float *__restrict__ feats, double *__restrict__ xy, float *__restrict__ wh,
@@ -318,6 +369,31 @@ extern "C" int ty1_decode_nms(const float *pred, int N, int S, int B, int C, int
         default: decode_nms_kernel<4><<<grid, block, lds, s>>>(pred, N, S, C, img_size, iou_thr, img_stride, vec2, boxes, score, cls, keep); break;
     }
     return ty1::check_launch("ty1_decode_nms");
+}
+
+extern "C" int ty1_head_decode_nms_f32(const float *part, const float *bias, float *y, int N, int S, int B, int C, int ldz,
+                                       int splits, int img_size, double iou_thr, double *boxes, float *score, int32_t *cls,
+                                       uint8_t *keep, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && C > 0 && img_size > 0 && splits > 0, "ty1_head_decode_nms: bad dimensions N=%d S=%d C=%d splits=%d", N, S, C, splits);
+    TY1_REQUIRE(S * S <= 64, "ty1_head_decode_nms: S*S=%d exceeds one wavefront (64 cells)", S * S);
+    TY1_REQUIRE(B >= 1 && B <= 4, "ty1_head_decode_nms: B=%d not in 1..4", B);
+    if (N == 0) return 0;
+    const int units = S * S * (C + 5 * B);
+    TY1_REQUIRE(part && boxes && score && cls && keep, "ty1_head_decode_nms: null pointer");
+    TY1_REQUIRE(ldz >= units, "ty1_head_decode_nms: ldz=%d < units=%d", ldz, units);
+    TY1_REQUIRE(((uintptr_t)boxes & 15) == 0, "ty1_head_decode_nms: boxes must be 16-byte aligned");
+    const size_t lds = ((size_t)2 * ((units + 1) & ~1) + 128) * sizeof(float);
+    TY1_REQUIRE(lds <= 64 * 1024, "ty1_head_decode_nms: C=%d needs %zu bytes of LDS (max 65536)", C, lds);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(N), block(kTailThreads);
+    ty1::ProfScope prof("head_decode_nms", s, 0.0, (double)N * (4.0 * units * (splits + (y ? 1.0 : 0.0)) + 41.0 * S * S * B));
+    switch (B) {
+        case 1: head_decode_nms_kernel<1><<<grid, block, lds, s>>>(part, bias, y, N, S, C, ldz, splits, img_size, iou_thr, boxes, score, cls, keep); break;
+        case 2: head_decode_nms_kernel<2><<<grid, block, lds, s>>>(part, bias, y, N, S, C, ldz, splits, img_size, iou_thr, boxes, score, cls, keep); break;
+        case 3: head_decode_nms_kernel<3><<<grid, block, lds, s>>>(part, bias, y, N, S, C, ldz, splits, img_size, iou_thr, boxes, score, cls, keep); break;
+        default: head_decode_nms_kernel<4><<<grid, block, lds, s>>>(part, bias, y, N, S, C, ldz, splits, img_size, iou_thr, boxes, score, cls, keep); break;
+    }
+    return ty1::check_launch("ty1_head_decode_nms_f32");
 }
 
 extern "C" int ty1_pack_detections(const double *boxes, const float *score, const int32_t *cls, const uint8_t *keep,

@@ -6,17 +6,9 @@
 // rest -> (S,S,4B); the activated tensor is cell-major (N,S,S,C+5B) = [cls C | conf B | box 4B].
 // z is reduced over the split-K partials into LDS once.
 #include "common.h"
+#include "head_math.h"
 
 namespace {
-
-// Both branches keep exp() finite: 1 / (1 + exp(-v)) alone returns exactly 0 from v < -88.7 on (exp overflows), while the
-// true value stays a positive fp32 number down to v = -103.9 - and a box width of exactly 0 is where yolo_loss' sqrt has
-// no finite derivative (csrc/loss.hip: dwh).
-__device__ __forceinline__ float sigmoidf_(float v) {
-    if (v >= 0.f) return 1.0f / (1.0f + expf(-v));
-    const float e = expf(v);
-    return e / (1.0f + e);
-}
 
 // grid (N, ceil(cells / kCellsPerBlock)): a block owns a few cells of one image, so even a small batch
 // spreads over the chip and the split-K reduction (tens of partial slabs) runs as independent loads.
@@ -28,40 +20,17 @@ __global__ __launch_bounds__(256) void head_activate_kernel(const float *__restr
     extern __shared__ float z[];                       // [cells_here][D]  cell-major, already in the output layout
     const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
     const int c0 = blockIdx.y * kCellsPerBlock, nc = min(kCellsPerBlock, cells - c0);
-    const int i1 = cells * C, i2 = i1 + cells * B;
     const size_t slab = (size_t)N * ldz;
     const float *pn = part + (size_t)n * ldz;
     for (int t = threadIdx.x; t < nc * D; t += blockDim.x) {
         const int lc = t / D, d = t - lc * D, cell = c0 + lc;
-        // planar Dense unit of (cell, channel d)
-        const int u = d < C ? cell * C + d : (d < C + B ? i1 + cell * B + (d - C) : i2 + cell * 4 * B + (d - C - B));
-        float a0 = bias ? bias[u] : 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= splits; s += 4) {
-            a0 += pn[(size_t)s * slab + u];
-            a1 += pn[(size_t)(s + 1) * slab + u];
-            a2 += pn[(size_t)(s + 2) * slab + u];
-            a3 += pn[(size_t)(s + 3) * slab + u];
-        }
-        for (; s < splits; ++s) a0 += pn[(size_t)s * slab + u];
-        z[t] = (a0 + a1) + (a2 + a3);
+        z[t] = ty1::reduce_unit(pn, slab, ty1::planar_unit(cell, d, cells, B, C), bias, splits);
     }
     __syncthreads();
     float *out = y + (size_t)n * units + (size_t)c0 * D;
     for (int t = threadIdx.x; t < nc * D; t += blockDim.x) {
         const int lc = t / D, d = t - lc * D;
-        const float *zc = z + lc * D;
-        float r;
-        if (d < C) {                                   // softmax over the C classes of the cell
-            float mx = zc[0];
-            for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
-            float sum = 0.f;
-            for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
-            r = expf(zc[d] - mx) / sum;
-        } else {
-            r = sigmoidf_(zc[d]);
-        }
-        out[t] = r;
+        out[t] = ty1::activate_channel(z + lc * D, d, C);
     }
 }
 

@@ -90,11 +90,20 @@ class DeviceModel:
         ws = self.workspace(x.shape[0])
         return self.head(self.backbone(x, ws), ws)
 
-    def detect(self, x, iou_thr=0.2):
-        """-> (boxes f64 (N,S*S*B,4), score, cls, keep) on the device."""
-        ws = self.workspace(x.shape[0])
-        y = self.head(self.backbone(x, ws), ws)
-        return ops.decode_nms(y, self.B, self.C, self.img_size, iou_thr, out=ws['det'])
+    FUSED_TAIL_MIN_BATCH = 16      # below it one workgroup per image leaves the split-K reduction too serial
+
+    def detect(self, x, iou_thr=0.2, want_y=False):
+        """-> (boxes f64 (N,S*S*B,4), score, cls, keep) on the device.  From FUSED_TAIL_MIN_BATCH images on, everything
+        behind the Dense GEMM is one launch (ty1_head_decode_nms_f32) and the head tensor stays in LDS unless want_y."""
+        N = x.shape[0]
+        ws = self.workspace(N)
+        feats = self.backbone(x, ws)
+        if N < self.FUSED_TAIL_MIN_BATCH:
+            return ops.decode_nms(self.head(feats, ws), self.B, self.C, self.img_size, iou_thr, out=ws['det'])
+        wt = self.dense_wt_bf16 if self.dtype == 'bf16' else self.dense_wt
+        part = ops.dense_splitk(feats, wt, self.units, part=ws['part'])
+        return ops.head_decode_nms(part, self.dense_b, self.S, self.B, self.C, self.img_size, iou_thr,
+                                   y=ws['y'] if want_y else None, out=ws['det'])
 
 
 class Trainer:

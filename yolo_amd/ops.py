@@ -236,6 +236,34 @@ def decode_nms(pred, B=2, C=20, img_size=448, iou_thr=0.2, out=None):
     return boxes, score, cls, keep
 
 
+def head_decode_nms(part, bias, S=7, B=2, C=20, img_size=448, iou_thr=0.2, y=None, out=None):
+    """Dense partials (splits,N,ldz) [+ bias] -> detections in ONE launch (head_activate + decode_nms, same bits).
+    y: optional (N,S,S,C+5B) f32 tensor that also receives the head tensor."""
+    _chk(part, torch.float32, 'part')
+    if part.dim() == 2:
+        part = part.unsqueeze(0)
+    splits, N, ldz = part.shape
+    units, slots = S * S * (C + 5 * B), S * S * B
+    if ldz < units:
+        raise ValueError(f'part: last dimension {ldz} is smaller than the {units} Dense units')
+    if bias is not None:
+        _chk(bias, torch.float32, 'bias')
+        if bias.numel() < units:
+            raise ValueError(f'bias: expected {units} values, got {bias.numel()}')
+    if y is not None:
+        _chk_out(y, torch.float32, (N, S, S, C + 5 * B), 'y')
+    if out is None:
+        dev = part.device
+        out = (torch.empty((N, slots, 4), dtype=torch.float64, device=dev), torch.empty((N, slots), dtype=torch.float32, device=dev),
+               torch.empty((N, slots), dtype=torch.int32, device=dev), torch.empty((N, slots), dtype=torch.uint8, device=dev))
+    boxes, score, cls, keep = out
+    _chk_out(boxes, torch.float64, (N, slots, 4), 'boxes'); _chk_out(score, torch.float32, (N, slots), 'score')
+    _chk_out(cls, torch.int32, (N, slots), 'cls'); _chk_out(keep, torch.uint8, (N, slots), 'keep')
+    _lib.call('ty1_head_decode_nms_f32', part.data_ptr(), _lib.ptr(bias), _lib.ptr(y), N, S, B, C, ldz, splits, int(img_size),
+              float(iou_thr), boxes.data_ptr(), score.data_ptr(), cls.data_ptr(), keep.data_ptr(), _lib.current_stream())
+    return boxes, score, cls, keep
+
+
 def pack_detections(boxes, score, cls, keep, out=None):
     """-> (N, slots, 6) f64 records x0,y0,x1,y1,score,class (-1 where not kept): the unit of the detection gather."""
     _chk(boxes, torch.float64, 'boxes'); _chk(score, torch.float32, 'score'); _chk(cls, torch.int32, 'cls'); _chk(keep, torch.uint8, 'keep')
