@@ -1106,12 +1106,22 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
     a.M = N * H * W;
     a.alpha = alpha;
     const bool p = pool != 0, of = out_f32 != 0;
+    static const char *force = ty1::dev_env("TY1_TILE");          // developer override
     if (Cin % 64 != 0) {               // 64-byte K chunks (32 bf16)
         TY1_REQUIRE(Cout % 64 == 0, "ty1_conv3x3_bf16: Cin=%d needs Cout %% 64 == 0 (got %d)", Cin, Cout);
+        if (force && !strcmp(force, "256x64")) return run_conv_bf16<4, 1, 2, 2, 16>("bk16_256x64", p, of, a, ws, ws_bytes, ws_need, s);
+        if (force && !strcmp(force, "128x64")) return run_conv_bf16<2, 1, 2, 2, 16>("bk16_128x64", p, of, a, ws, ws_bytes, ws_need, s);
+        // a long M (112x112x32->64 at 128 images): 256-row tiles read each weight chunk once per 256 rows (116 -> 109 us)
+        if (((long long)a.M + 255) / 256 >= 2 * num_cus() && !ty1::dev_env("TY1_OLD_RULES"))
+            return run_conv_bf16<4, 1, 2, 2, 16>("bk16_256x64", p, of, a, ws, ws_bytes, ws_need, s);
         return run_conv_bf16<2, 1, 2, 2, 16>("bk16_128x64", p, of, a, ws, ws_bytes, ws_need, s);
     }
     const long long mt128 = ((long long)a.M + 127) / 128;
-    static const char *force = ty1::dev_env("TY1_TILE");          // developer override
+#ifdef TY1_DEV_STAMPS       // tile shapes that only the sweeps of the dev build instantiate
+    if (force && !strcmp(force, "128x256") && Cout % 256 == 0) return run_conv_bf16<2, 4, 2, 2, 32>("128x256", p, of, a, ws, ws_bytes, ws_need, s);
+    if (force && !strcmp(force, "256x64") && Cout % 64 == 0) return run_conv_bf16<4, 1, 2, 2, 32>("256x64", p, of, a, ws, ws_bytes, ws_need, s);
+#endif
+    if (force && !strcmp(force, "256x128") && Cout % 128 == 0) return run_conv_bf16<4, 2, 2, 2, 32>("256x128", p, of, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "128x128") && Cout % 128 == 0) return run_conv_bf16<2, 2, 2, 2, 32>("128x128", p, of, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "128x64") && Cout % 64 == 0) return run_conv_bf16<2, 1, 2, 2, 32>("128x64", p, of, a, ws, ws_bytes, ws_need, s);
     if (force && !strcmp(force, "64x64") && Cout % 64 == 0) return run_conv_bf16<1, 1, 2, 2, 32>("64x64", p, of, a, ws, ws_bytes, ws_need, s);
@@ -1121,6 +1131,10 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
     if (Cout % 128 == 0 && (mt128 * (Cout / 128) >= 2 * num_cus() || (Cin >= 512 && mt128 * (Cout / 64) < 2 * num_cus())))
         return run_conv_bf16<2, 2, 2, 2, 32>("128x128", p, of, a, ws, ws_bytes, ws_need, s);
     TY1_REQUIRE(Cout % 64 == 0, "ty1_conv3x3_bf16: Cout=%d must be a multiple of 64 when Cin >= 32", Cout);
+    // deep K, too few 128x64 tiles for four rounds (7x7x512->1024 at 128 images: 784): one 256x128 workgroup per CU with
+    // 128x64 per wave, everything K-split (measured 93 -> 84 us; the same tile loses 10-20 % on the layers with more tiles)
+    if (Cout % 128 == 0 && Cin >= 512 && a.M >= 4096 && mt128 * (Cout / 64) < 4 * num_cus() && !ty1::dev_env("TY1_OLD_RULES"))
+        return run_conv_bf16<4, 2, 2, 2, 32>("256x128", p, of, a, ws, ws_bytes, ws_need, s);
     if (mt128 * (Cout / 64) >= 2 * num_cus() || a.M >= 4096 * 2)
         return run_conv_bf16<2, 1, 2, 2, 32>("128x64", p, of, a, ws, ws_bytes, ws_need, s);
     return run_conv_bf16<1, 1, 2, 2, 32>("64x64", p, of, a, ws, ws_bytes, ws_need, s);
