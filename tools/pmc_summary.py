@@ -26,7 +26,7 @@ for k, v in sorted(agg.items()):
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 3 and sys.argv[2] == '--traffic':      # also write the per-launch HBM bytes bench.py quotes (profiles/pmc_traffic.json)
     tag = os.path.basename(os.path.normpath(root))
-    tr = {'source': f'profiles/{tag}_bench_b64_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per '
+    tr = {'source': f'profiles/{tag}_pmc.json of that run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per '
                     'MI355X_MICROARCH.md HBM section)', 'kernels': {}}
     for k, row in out.items():
         if 'hbm_read_MB' in row and 'hbm_write_MB' in row:
