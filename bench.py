@@ -58,8 +58,11 @@ class Ctx:
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         if self.world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device('cuda', self.local_rank)
+        # one rank per GPU; the modulo only matters for the rehearsal of N ranks on fewer cards (--backend gloo)
+        self.dev_index = self.local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device('cuda', self.dev_index)
+        self.backend = args.backend
         self.multi = self.world > 1 or args.force_gather
         self.dist = None
         self.rccl_world = 1
@@ -67,14 +70,23 @@ class Ctx:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29533')
-            dist.init_process_group('nccl', device_id=self.dev, rank=self.rank, world_size=self.world)
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=self.dev, rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
             self.rccl_world = dist.get_world_size()       # what RCCL's communicator reports, not the env
+
+    def barrier(self):
+        if self.backend == 'nccl':
+            self.dist.barrier(device_ids=[self.dev_index])
+        else:
+            self.dist.barrier()
 
     def sync(self):
         torch.cuda.synchronize(self.dev)
         if self.multi:
-            self.dist.barrier(device_ids=[self.local_rank])
+            self.barrier()
             torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, seconds):
@@ -86,7 +98,7 @@ class Ctx:
 
     def close(self):
         if self.multi:
-            self.dist.barrier(device_ids=[self.local_rank])
+            self.barrier()
             self.dist.destroy_process_group()
 
 
@@ -247,7 +259,12 @@ def run_infer(ctx, args, dtype, N, detailed=True):
         boxes, score, cls, keep = model.detect(x)
         if ctx.multi:                                  # detection gather: fixed-size records, one collective
             ops.pack_detections(boxes, score, cls, keep, out=rec)
-            ctx.dist.all_gather_into_tensor(gathered, rec)
+            if ctx.backend == 'nccl':
+                ctx.dist.all_gather_into_tensor(gathered, rec)
+            else:                                      # rehearsal backend: staged through the host
+                host = torch.empty(gathered.shape, dtype=gathered.dtype)
+                ctx.dist.all_gather_into_tensor(host, rec.cpu())
+                gathered.copy_(host)
         state['keep'] = keep
 
     est = 1.65 if dtype == 'f32' else 0.8
@@ -273,7 +290,7 @@ def run_infer(ctx, args, dtype, N, detailed=True):
         'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS[dtype] * 1e12), 4),
     }
     if ctx.multi:
-        res['rccl'] = {'backend': 'nccl (RCCL)', 'world_size_reported': ctx.rccl_world,
+        res['rccl'] = {'backend': 'nccl (RCCL)' if ctx.backend == 'nccl' else ctx.backend, 'world_size_reported': ctx.rccl_world,
                        'gathered_records_shape': list(gathered.shape),
                        'gathered_kept_boxes': int((gathered[..., 5] >= 0).sum().item())}
     if 'roofline' in m:
@@ -359,7 +376,7 @@ def run_train(ctx, args, N, detailed=True):
         'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS['f32'] * 1e12), 4),
     }
     if ctx.multi:
-        res['rccl'] = {'backend': 'nccl (RCCL)', 'world_size_reported': ctx.rccl_world}
+        res['rccl'] = {'backend': 'nccl (RCCL)' if ctx.backend == 'nccl' else ctx.backend, 'world_size_reported': ctx.rccl_world}
     if 'roofline' in m:
         res['roofline'] = m['roofline']
     if detailed:
@@ -414,9 +431,15 @@ def main():
     ap.add_argument('--no-also', action='store_true', help='skip the configs[2] / configs[3] measurements under "also"')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')
     ap.add_argument('--settle-ms', type=float, default=200.0, help='untimed steps after the warm-up until the clocks have settled')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='collective backend; gloo only to rehearse the N-rank launch path on a box with fewer GPUs than ranks '
+                         '(RCCL refuses two ranks on one device): numbers from such a run mean nothing')
     ap.add_argument('--force-gather', action='store_true',
                     help='developer check: run the N>1 code path (process group, detection gather, all-reduce) on one rank')
     args = ap.parse_args()
+    if os.environ.get('TY1_BENCH_WATCHDOG'):          # developer aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['TY1_BENCH_WATCHDOG']), repeat=True, file=sys.stderr)
     ctx = Ctx(args)
     headline_is_default = args.mode == 'infer' and args.dtype == 'f32'
     prm = x_cpu = None
@@ -439,6 +462,11 @@ def main():
         sub.steps, sub.warmup, sub.settle_ms = min(args.steps, 50), min(args.warmup, 10), min(args.settle_ms, 100.0)
         for key, fn in (('configs[2] bf16 inference', lambda: run_infer(ctx, sub, 'bf16', 128)[0]),
                         ('configs[3] training step', lambda: run_train(ctx, sub, 32))):
+            if ctx.multi and ctx.backend != 'nccl' and 'training' in key:
+                # the rehearsal backend stalls in gloo's device-tensor all-reduce of the 74 MB bucket when two ranks share a
+                # card; the two-rank training step itself is covered by tests/test_gpu_ddp.py
+                also[key] = {'skipped': 'rehearsal backend (gloo): training all-reduce not rehearsed here'}
+                continue
             torch.cuda.empty_cache()
             r = fn()
             r.pop('kernels', None)
