@@ -25,12 +25,12 @@ N_CONV = 8
 N_POOL = 6
 
 
-def conv_block_ref(x_nchw, w_hwio, gamma, beta, mean, var, pool):
+def conv_block_ref(x_nchw, w_hwio, gamma, beta, mean, var, pool, alpha=0.1):
     w = torch.from_numpy(np.ascontiguousarray(w_hwio)).permute(3, 2, 0, 1).contiguous()   # OIHW
     y = F.conv2d(x_nchw, w, bias=None, stride=1, padding=1)
     g, b, m, v = (torch.from_numpy(np.asarray(a, np.float32)).reshape(1, -1, 1, 1) for a in (gamma, beta, mean, var))
     y = (y - m) / torch.sqrt(v + BN_EPS) * g + b          # Keras BatchNormalization, inference
-    y = F.leaky_relu(y, 0.1)
+    y = torch.where(y > 0, y, y * alpha)                  # LeakyReLU(alpha); the model's own slope is 0.1
     if pool:
         y = F.max_pool2d(y, 2, 2)
     return y

@@ -103,7 +103,7 @@ def test_decode_nms_edge_cases():
 
 
 # ------------------------------------------------------------------------------- conv blocks
-def _conv_case(N, H, cin, cout, pool, seed, use_ws=False):
+def _conv_case(N, H, cin, cout, pool, seed, use_ws=False, alpha=0.1):
     rng = np.random.default_rng(seed)
     x = rng.random((N, H, H, cin)).astype(np.float32)
     w = P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)
@@ -112,13 +112,13 @@ def _conv_case(N, H, cin, cout, pool, seed, use_ws=False):
     mean = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
     var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     xt = torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
-    ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool).permute(0, 2, 3, 1).contiguous().numpy()
+    ref = model_ref.conv_block_ref(xt, w, gamma, beta, mean, var, pool, alpha).permute(0, 2, 3, 1).contiguous().numpy()
     scale, shift = ops.fold_bn(gamma, beta, mean, var)
     ws = None
     if use_ws:      # the K-split tail path (csrc/conv_gemm.hip plan_tail); poison the scratch to catch unwritten partials
         nbytes = ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool)
         ws = torch.full((max(nbytes, 16) // 4,), float('nan'), dtype=torch.float32, device=DEV)
-    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool, workspace=ws).cpu().numpy()
+    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool, alpha=alpha, workspace=ws).cpu().numpy()
     return got, ref
 
 
@@ -147,6 +147,16 @@ def test_conv_block_vs_oracle(N, H, cin, cout, pool, use_ws):
     # fp32 bar of north_star: 1e-3 relative.  Measured error is ~1e-6 (exact-f32 MFMA, fp32 accumulate).
     np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-5)
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('alpha', [0.0, 0.5, 1.0, 1.5, -0.25])
+@pytest.mark.parametrize('N,H,cin,cout,pool', [(1, 36, 3, 16, True), (1, 40, 3, 16, False), (1, 20, 16, 32, True),
+                                               (2, 10, 32, 64, True), (1, 6, 64, 128, False)])
+def test_conv_block_other_slopes(N, H, cin, cout, pool, alpha):
+    """The model's LeakyReLU slope is 0.1; the kernels take short cuts that depend on it (pool before activation needs
+    alpha >= 0, max(m, alpha*m) needs 0 < alpha <= 1) and must fall back to the plain order outside those ranges."""
+    got, ref = _conv_case(N, H, cin, cout, pool, seed=7 + cin, alpha=alpha)
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-5)
 
 
 # ------------------------------------------------------------------------------- dense + head

@@ -397,9 +397,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
 // ------------------------------------------------------------------------------------------------
 // First layer (Cin = 3, K = 27 -> 28) as a persistent kernel on v_mfma_f32_16x16x4_f32: same arithmetic as
 // conv3x3_c3_kernel (conv_gemm.hip: halo tile in LDS, 7 weight registers per 16 channels, one pool window per
-// lane), but a workgroup walks 16 x 64 pixel patches, fetches the NEXT patch's halo with 16-byte loads into
-// registers while the current patch multiplies, and stores it to the other LDS buffer afterwards.  The layer is
-// bound by its 406 MB of HBM traffic at batch 64, so what matters is that loads are wide and always in flight.
+// lane), but a workgroup walks 16 x 64 pixel patches and moves the NEXT patch's halo into the other LDS buffer by
+// LDS-DMA while the current patch multiplies.  The layer is bound by its 406 MB of HBM traffic at batch 64 as much
+// as by its MFMAs, so what matters is that loads are wide, always in flight, and that nothing drains the stores.
 // Needs W % 4 == 0 and a 16-byte aligned input (an image row is then a whole number of float4).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -407,8 +407,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int C3_TH = 16, C3_TW = 64;
 constexpr int C3_ROW = 208;                                  // LDS floats per halo row (200 used); 208 % 32 == 16
 constexpr int C3_V4 = 50;                                    // float4 per halo row: floats 3*x0 - 4 .. 3*x0 + 195
-constexpr int C3_ITEMS = (C3_TH + 2) * C3_V4;                // 900
-constexpr int C3_PER_THREAD = (C3_ITEMS + 255) / 256;        // 4
 
 template <bool POOL, int NT, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -453,23 +451,17 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         sh[j] = shift[16 * j + i16];
     }
 
-    // Halo staging.  Piece i = tid + 256k of a patch is float4 c = i % 50 of halo row rr = i / 50: image row
-    // y0 - 1 + rr, floats 3*x0 - 4 + 4c ...  The loads go through a buffer resource that spans ONE image, so rows above
-    // and below the image fall outside it and read as zero; only the left / right border needs a test.
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 stage[C3_PER_THREAD];
-    int st_rr[C3_PER_THREAD], st_c[C3_PER_THREAD];
+    // Halo staging by LDS-DMA (buffer_load_dwordx4 ... lds).  Halo row rr = image row y0 - 1 + rr, floats 3*x0 - 4 ...
+    // 3*x0 + 195, is ONE wave instruction: lane c < 50 moves float4 c straight to tile[buf][rr * C3_ROW + 4c]; wave w takes
+    // rows w, w + 4, ...  The loads go through a buffer resource that spans ONE image, so rows above and below the image
+    // fall outside it and land as zeros; only the left / right border needs a test.  No staging registers, no ds_write,
+    // and - the point - no compiler-placed wait: with register staging hipcc put `s_waitcnt vmcnt(3..0)` in front of the
+    // four ds_writes at the end of a patch, which on this hardware also drains the 16 epilogue stores issued since the
+    // loads (stores count in vmcnt), one exposed HBM write latency per patch.  Here a wave waits `vmcnt(stores per patch)`:
+    // its DMAs, which are older than those stores, have landed; the stores stay in flight across the barrier.
     const int row_f = 3 * W;                                 // floats per image row
-    unsigned st_off[C3_PER_THREAD];                          // byte offset of the piece in a patch at (y0, x0) = (1, 0)
-    int st_g[C3_PER_THREAD];                                 // its float index in the image row for x0 = 0
-#pragma unroll
-    for (int k = 0; k < C3_PER_THREAD; ++k) {
-        const int i = tid + 256 * k;
-        st_rr[k] = i < C3_ITEMS ? i / C3_V4 : -1;
-        st_c[k] = i - (i / C3_V4) * C3_V4;
-        st_g[k] = i < C3_ITEMS ? 4 * st_c[k] - 4 : -0x40000000;     // a dead piece never passes the border test
-        st_off[k] = (unsigned)((st_rr[k] * row_f + 4 * st_c[k] - 4) * 4);
-    }
+    const int c_g = lane < C3_V4 ? 4 * lane - 4 : -0x40000000;      // float index in the image row for x0 = 0 (a dead lane never passes the border test)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
     auto decode = [&](int p, int &n, int &y0, int &x0) {
         const int tx = p % tiles_x;
         const int r = p / tiles_x;
@@ -479,7 +471,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         x0 = tx * C3_TW;
     };
     constexpr unsigned kOOB = 0xFFFFFFFFu;
-    auto fetch = [&](int p) {
+    auto fetch = [&](int p, int buf) {
         p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
         int n, y0, x0;
         decode(p, n, y0, x0);
@@ -487,18 +479,22 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         const bool live = p < patches;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(x) + (live ? (long long)n * H * row_f : 0ll), 0, live ? H * row_f * 4 : 0, 0x00020000);
-        const unsigned patch_off = (unsigned)(((y0 - 1) * row_f + 3 * x0) * 4);   // wraps for y0 = 0: outside the resource
+        const unsigned patch_off = (unsigned)((y0 - 1) * row_f + 3 * x0 + c_g) * 4u;   // wraps for y0 = 0: outside the resource
+        const bool in_row = (unsigned)(c_g + 3 * x0) < (unsigned)row_f;
+        if (lane < C3_V4) {
 #pragma unroll
-        for (int k = 0; k < C3_PER_THREAD; ++k) {
-            const bool in_row = (unsigned)(st_g[k] + 3 * x0) < (unsigned)row_f;
-            stage[k] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(in_row ? st_off[k] + patch_off : kOOB), 0, 0);
+            for (int k = 0; k < (C3_TH + 2 + 3) / 4; ++k) {
+                const int rr = __builtin_amdgcn_readfirstlane(wave) + 4 * k;
+                if (rr < C3_TH + 2)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)&tile[buf][rr * C3_ROW], 16,
+                                                             (int)(in_row ? patch_off + (unsigned)(rr * row_f * 4) : kOOB), 0, 0, 0);
+            }
         }
     };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < C3_PER_THREAD; ++k)
-            if (st_rr[k] >= 0) *reinterpret_cast<u32x4 *>(&tile[buf][st_rr[k] * C3_ROW + 4 * st_c[k]]) = stage[k];
-    };
+    // stores a wave issues per patch (they follow the patch's DMAs in program order); vmcnt holds at most 63
+    constexpr int kStoresPerPatch = 16 * NT * (POOL ? 1 : 4) < 63 ? 16 * NT * (POOL ? 1 : 4) : 63;
+    auto wait_halo = [] { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStoresPerPatch) : "memory"); };
+    auto wg_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // pixel of this lane inside an M-tile: window (i16>>2) of 4, position q = i16&3 in the 2x2 window
     const int q = i16 & 3;
@@ -534,14 +530,15 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         stamp[(long long)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 
+    const bool act_max = alpha > 0.f && alpha <= 1.f;
     int p = blockIdx.x;
-    fetch(p);
-    store(0);
-    __syncthreads();
+    fetch(p, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
     int buf = 0;
     for (; p < patches; p += gridDim.x) {
         C3_STAMP(ts0);
-        fetch(p + gridDim.x);                                // in flight during the MFMAs (nothing past the end)
+        fetch(p + gridDim.x, buf ^ 1);                       // lands during the MFMAs (zeros past the end); that buffer was last read before the previous barrier
         C3_STAMP(ts1);
         int n, y0, x0;
         decode(p, n, y0, x0);
@@ -603,8 +600,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                     }
             }
         };
-        auto finish = [&](auto full_c, int t2, const f32x4 (&acc)[2][NT]) {
-            constexpr bool FULL = decltype(full_c)::value;
+        auto finish = [&](auto full_c, auto act_c, int t2, const f32x4 (&acc)[2][NT]) {
+            constexpr bool FULL = decltype(full_c)::value, ACT_MAX = decltype(act_c)::value;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = t2 + u, pr = t >> 3, wc = t & 7;
@@ -615,8 +612,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                     for (int r = 0; r < 4; ++r) z[r] = acc[u][j][r] * sc[j] + sh[j];
                     if (POOL) {
                         // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
-                        const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
-                        const float v = m > 0.f ? m : m * alpha;
+                        // (v_max3 + v_max; for 0 < alpha <= 1 LeakyReLU(m) is max(m, alpha * m), bit for bit incl. -0, inf and
+                        //  NaN: two VALU ops instead of three - every one of them is paid for in matrix-pipe cycles)
+                        const float m = fmaxf(fmaxf(fmaxf(z[0], z[1]), z[2]), z[3]);
+                        const float v = ACT_MAX ? fmaxf(m, m * alpha) : (m > 0.f ? m : m * alpha);
                         const int tile_off = pr * (int)row_b + 4 * wc * (int)px_b + 16 * (int)OSZ * j;
                         if constexpr (FULL) {
                             put(v, lane_off, tile_off);
@@ -641,7 +640,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                 }
             }
         };
-        auto patch_body = [&](auto full_c) {
+        auto patch_body = [&](auto full_c, auto act_c) {
             f32x4 accA[2][NT], accB[2][NT];
             float avA[KS][2], avB[KS][2];
             load_a(0, avA);
@@ -654,20 +653,25 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                 if (it < 3) load_a(4 * it + 4, avA);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(avB, accB);
-                finish(full_c, 4 * it, accA);
+                finish(full_c, act_c, 4 * it, accA);
                 __builtin_amdgcn_sched_barrier(0);
                 if (it < 3) load_a(4 * it + 6, avB);
                 __builtin_amdgcn_sched_barrier(0);
                 if (it < 3) compute(avA, accA);
-                finish(full_c, 4 * it + 2, accB);
+                finish(full_c, act_c, 4 * it + 2, accB);
             }
         };
-        if (full) patch_body(std::true_type{});
-        else patch_body(std::false_type{});
+        if (POOL && act_max) {
+            if (full) patch_body(std::true_type{}, std::true_type{});
+            else patch_body(std::false_type{}, std::true_type{});
+        } else {
+            if (full) patch_body(std::true_type{}, std::false_type{});
+            else patch_body(std::false_type{}, std::false_type{});
+        }
         C3_STAMP(ts2);
-        store(buf ^ 1);                                      // that buffer was last read before the previous barrier
+        wait_halo();
         C3_STAMP(ts3);
-        __syncthreads();
+        wg_barrier();
         C3_STAMP(ts4);
         buf ^= 1;
         acc_fetch += ts1 - ts0; acc_mma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3; ++n_done;
