@@ -407,15 +407,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int C3_TH = 16, C3_TW = 64;
 constexpr int C3_ROW = 208;                                  // LDS floats per halo row (200 used); 208 % 32 == 16
 constexpr int C3_V4 = 50;                                    // float4 per halo row: floats 3*x0 - 4 .. 3*x0 + 195
+constexpr int C3_TILE = (C3_TH + 2) * C3_ROW;                // floats of one halo buffer
+constexpr int C3_ONES = 592;                                 // floats of 1.0 behind it (>= 2 * C3_ROW + 24 * 7 + 1), see FOLD
+constexpr int C3_BUF = C3_TILE + C3_ONES;
 
 template <bool POOL, int NT, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                           void *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
-                                                          int tiles_x, int tiles_y, int patches, long long *stamp) {
-    __shared__ __attribute__((aligned(16))) float tile[2][(C3_TH + 2) * C3_ROW];
+                                                          int tiles_x, int tiles_y, int patches, long long *stamp, int dbg) {
+    // developer knock-outs (dev build only; same instruction stream, no memory traffic): 1 drop the output stores, 2 drop the halo fetch
+#ifdef TY1_DEV_STAMPS
+#define C3_DBG(bit) ((dbg & (bit)) != 0)
+#else
+#define C3_DBG(bit) false
+#endif
+    __shared__ __attribute__((aligned(16))) float tile[2][C3_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
+    // FOLD (f32): the folded BatchNorm rides in the MFMAs - the weights are multiplied by the channel's scale when they
+    // are loaded, and the shift is the weight of the K pad slot k = 27, whose A operand is a 1.0 read from a block of
+    // ones behind each halo buffer (every M-tile adds its own compile-time offset to the lane's address, so the block
+    // covers the largest one).  The accumulator then IS scale * conv + shift and the epilogue loses its four v_fma per
+    // tile: with exact-f32 MFMAs every vector instruction between two of them costs the matrix pipe ~8 cycles, and a
+    // tile is only 7 MFMAs (measured per tile: 224 MFMA cycles + 99, of which the four v_fma were 34).  Results differ
+    // from (conv * scale + shift) in the last bit or two, far inside the 1e-3 bar.  The bf16 variant keeps the separate
+    // scale: its weights are rounded to bf16 and must be the oracle's rounded weights.
+    constexpr bool FOLD = !OUT_BF16;
 
     // f32 (exact):  7 x v_mfma_f32_16x16x4_f32 per 16-pixel tile, lane quarter kq supplies k = 4*ks + kq of step ks.
     // OUT_BF16 (first layer of the bf16 network): image and weights are rounded to bf16 on the fly and a tile is
@@ -429,7 +447,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = k_of(ks);
-            wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] : 0.f;
+            if (FOLD) wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] * scale[16 * j + i16] : (k == 27 ? shift[16 * j + i16] : 0.f);
+            else wreg[j][ks] = k < 27 ? w[(16 * j + i16) * 27 + k] : 0.f;
         }
     bf16x8 wb[NT];
 #pragma unroll
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         n = __builtin_amdgcn_readfirstlane(n); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);
         const bool live = p < patches;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(x) + (live ? (long long)n * H * row_f : 0ll), 0, live ? H * row_f * 4 : 0, 0x00020000);
+            const_cast<float *>(x) + (live ? (long long)n * H * row_f : 0ll), 0, live && !C3_DBG(2) ? H * row_f * 4 : 0, 0x00020000);
         const unsigned patch_off = (unsigned)((y0 - 1) * row_f + 3 * x0 + c_g) * 4u;   // wraps for y0 = 0: outside the resource
         const bool in_row = (unsigned)(c_g + 3 * x0) < (unsigned)row_f;
         if (lane < C3_V4) {
@@ -503,7 +522,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     // of a row is image float 3*x0 - 4, so pixel x0 - 1 starts at 1.  Every other tile is a compile-time offset.
     int a_addr[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_addr[ks] = (4 * wave + lane_py) * C3_ROW + lane_px * 3 + 1 + koff[ks];
+    for (int ks = 0; ks < KS; ++ks)
+        a_addr[ks] = (FOLD && k_of(ks) == 27) ? C3_TILE : (4 * wave + lane_py) * C3_ROW + lane_px * 3 + 1 + koff[ks];
     const float *lds = &tile[0][0];
 
     // Output: lane holds channel 16j + i16 of pool window kq (POOL) / of the 2x2 pixels of window kq, for every
@@ -531,6 +551,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     }
 
     const bool act_max = alpha > 0.f && alpha <= 1.f;
+    if (FOLD)
+        for (int i = tid; i < C3_ONES; i += 256) tile[0][C3_TILE + i] = tile[1][C3_TILE + i] = 1.f;
     int p = blockIdx.x;
     fetch(p, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         const long long o_org = (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
         const long long o_left = (y_total - o_org) * OSZ;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            static_cast<char *>(y) + o_org * OSZ, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+            static_cast<char *>(y) + o_org * OSZ, 0, C3_DBG(1) ? 0 : (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
         auto put = [&](float v, unsigned off, int soff) {
             if constexpr (OUT_BF16) __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, soff, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, soff, 0);
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * kq;
         int ab[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ab[ks] = a_addr[ks] + buf * ((C3_TH + 2) * C3_ROW);
+        for (int ks = 0; ks < KS; ++ks) ab[ks] = a_addr[ks] + buf * C3_BUF;
 
         // Two M-tiles (independent MFMA chains) per step; the BN / LeakyReLU / pool / store of a step is written
         // after the MFMAs of the NEXT step so that the scheduler can run it under them.
@@ -572,7 +594,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int t = t2 + u, pr = t >> 3, wc = t & 7;
+#if defined(C3_KO) && (C3_KO & 2)
+                    av[ks][u] = __int_as_float(ab[ks] + t);
+#else
                     av[ks][u] = lds[ab[ks] + 2 * pr * C3_ROW + 24 * wc];   // window 4*wc -> pixel 8*wc -> float 24*wc
+#endif
                 }
         };
         auto compute = [&](const float (&av)[KS][2], f32x4 (&acc)[2][NT]) {
@@ -602,6 +628,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         };
         auto finish = [&](auto full_c, auto act_c, int t2, const f32x4 (&acc)[2][NT]) {
             constexpr bool FULL = decltype(full_c)::value, ACT_MAX = decltype(act_c)::value;
+#if defined(C3_KO) && (C3_KO & 1)
+            for (int u = 0; u < 2; ++u) for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[u][j]));
+            return;
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int t = t2 + u, pr = t >> 3, wc = t & 7;
@@ -609,7 +639,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
                 for (int j = 0; j < NT; ++j) {
                     float z[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = acc[u][j][r] * sc[j] + sh[j];
+                    for (int r = 0; r < 4; ++r) z[r] = FOLD ? acc[u][j][r] : acc[u][j][r] * sc[j] + sh[j];
                     if (POOL) {
                         // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
                         // (v_max3 + v_max; for 0 < alpha <= 1 LeakyReLU(m) is max(m, alpha * m), bit for bit incl. -0, inf and
@@ -677,6 +707,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
         acc_fetch += ts1 - ts0; acc_mma += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3; ++n_done;
     }
 #undef C3_STAMP
+#undef C3_DBG
     if (stamp && tid == 0) {
         stamp[(long long)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         stamp[(long long)blockIdx.x * 8 + 1] = acc_mma;
@@ -774,14 +805,16 @@ int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, co
     TY1_REQUIRE(patches < (1ll << 31), "ty1_conv3x3(c3): too many patches");
     TY1_REQUIRE((long long)H * W * 12 < (1ll << 31), "ty1_conv3x3(c3): one image must stay below 2 GiB");
     const int P = (int)patches, nt = Cout / 16;
-    // persistent grid: as many workgroups as stay resident (30 KB of LDS, <= 128 registers: four per CU)
+    const char *dbg_env = ty1::dev_env("TY1_C3_DBG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    // persistent grid: as many workgroups as stay resident (35 KB of LDS, <= 128 registers: four per CU)
 #define TY1_C3P(PL, NTV, OB)                                                                                          \
     do {                                                                                                              \
         static const int per_cu = resident_blocks(conv3x3_c3p_kernel<PL, NTV, OB>, 4, "TY1_C3_BLOCKS");               \
         const long long want = (long long)per_cu * cu_count();                                                        \
         const long long nblk = patches < want ? patches : want;                                                       \
         conv3x3_c3p_kernel<PL, NTV, OB><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                   \
-            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr); \
+            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr, dbg); \
     } while (0)
 #define TY1_C3P_NT(PL, OB)                                                                                            \
     do {                                                                                                              \
