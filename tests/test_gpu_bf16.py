@@ -80,6 +80,20 @@ def test_conv_block_bf16_vs_oracle(N, H, cin, cout, pool, out_f32, use_ws):
         assert (got == bf16_round(ref)).mean() > 0.99
 
 
+# batches large enough for the halo kernels (csrc/conv_halo.hip; the dispatcher takes them once a layer has at least four
+# work items per CU): weights resident (Cin = 32), streamed weights with one and with two K chunks and channel tiles
+HALO_CASES = [(44, 112, 32, 64), (80, 56, 64, 128), (40, 56, 128, 256)]
+
+
+@pytest.mark.parametrize('N,H,cin,cout', HALO_CASES)
+def test_conv_block_bf16_halo_vs_oracle(N, H, cin, cout):
+    got, ref = _case(N, H, cin, cout, True, False, seed=3 * cin + cout, use_ws=False)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
+    assert (got == bf16_round(ref)).mean() > 0.99
+
+
 def test_cast_bf16_round_to_nearest_even():
     x = torch.randn(100003, device=DEV) * 37.0
     assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))

@@ -1,0 +1,363 @@
+// Pooled 3x3 conv + folded BN + LeakyReLU blocks of the bf16 network on an LDS-resident input halo
+// (v_mfma_f32_32x32x16_bf16; /root/reference/models/model_tiny_yolov1.py:52-76, the blocks with Cin = 32 ... 128).
+//
+// Why a second kernel next to conv_persist_kernel (conv_gemm.hip): that loop fetches a 128-byte row of A per output
+// pixel, tap and K chunk - the im2col matrix, every activation nine times - and in bf16 the fetch, not the matrix pipe,
+// bounds it: per 16 MFMAs (512 matrix cycles) a wave issues 8 LDS-DMA instructions at 60-185 cycles each.
+// Here a workgroup owns a PH x PW patch of pre-pool pixels (GEMM rows in pool-window order, as there) and all of Cin:
+//   * the (PH+2) x (PW+2) halo of a 64-byte or 128-byte K chunk is moved to LDS ONCE (LDS-DMA, zeros outside the image)
+//     and serves all nine taps: a tap is a constant shift of the fragment address;
+//   * the weights stream through a ring of three stages (one tap x BN channels x chunk), fetched two stages ahead
+//     (counted vmcnt, raw s_barrier), or - when all of them fit (Cin = 32: 36 KB) - are loaded once and stay;
+//   * the halo of the next chunk / next patch lands in the other halo buffer while this one multiplies.
+// LDS-DMA bytes per MFMA drop from 512 to 160-270.  Bank conflicts: a pixel's (a weight row's) 16-byte K slots are
+// XOR-swizzled with the low bits of its index on the source side of the DMA; a fragment read is
+// base(lane, tap) ^ (k-step << 5) (+ immediate); switching halo buffers adds +-(buffer size) to the 18 bases.
+// Epilogue as in conv_persist_kernel: BN, 2x2 max over four accumulator registers, LeakyReLU once, bf16 store.
+#include "common.h"
+
+#include <cstdint>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *lds_ptr;
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+constexpr unsigned kNoStore = 0x80000000u;       // (+ a small lane offset stays outside every output resource)
+
+struct HaloArgs {
+    const void *x, *w;
+    const float *scale, *shift;
+    void *y;
+    int NB, H, W, Cin, Cout;
+    float alpha;
+    int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
+};
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to nearest even
+    const __bf16 hv = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, hv);
+}
+
+// CK: channels per K chunk (32 or 64).  BN: output channels per item.  PH x PW: patch (even, PH * PW <= 64 * WAVES_M).
+// RES_B: Cin == CK and Cout == BN - the whole weight tensor (9 x BN x CK) is loaded once and stays in LDS.
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_halo_bf16_kernel(const HaloArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int CKB = CK * 2, NSLOT = CKB / 16, NS16 = CK / 16;      // bytes, 16-byte slots, k16 steps per chunk row
+    constexpr int HWD = PW + 2, HPIX = (PH + 2) * HWD;                 // halo width, halo pixels
+    constexpr int PIXPP = 1024 / CKB;                                  // pixels (rows) per 1 KiB DMA piece
+    // swizzle key of row (pixel / weight row) idx: rows idx and idx + RPW start on the same bank, so the key changes every
+    // RPW rows and 16 consecutive rows give 16 distinct (start bank, slot) pairs = all 64 banks for a ds_read_b128 group
+    constexpr int RPW = 256 / CKB;
+    auto key_of = [](int idx) { return (idx / RPW) & (NSLOT - 1); };
+    constexpr int HP = (HPIX + PIXPP - 1) / PIXPP;                     // halo pieces
+    constexpr int HPW = (HP + NW - 1) / NW;                            // ... per wave
+    constexpr int HALO1 = HP * 1024;                                   // byte distance of the two halo buffers
+    constexpr int TS = RES_B ? 9 : 1, NSC = 9 / TS, NRING = RES_B ? 1 : 3;   // taps per stage, stages per chunk, ring
+    constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NW;    // bytes, pieces, pieces per wave
+    constexpr int BOFF = HALO1 + HP * 1024;
+    constexpr int MPIX = PH * PW, WINS = MPIX / 4;
+    static_assert(BN == 64 * WAVES_N, "a wave owns 64 x 64 of the tile");
+    static_assert(MPIX <= 64 * WAVES_M && MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0, "patch shape");
+    static_assert(BP % NW == 0, "weight pieces divide among the waves");
+    static_assert(RES_B || HPW <= NSC, "one halo piece per wave and stage");
+    static_assert(BOFF + NRING * STAGE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char lds[BOFF + NRING * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int G = gridDim.x;
+    const int nch = a.Cin / CK;
+    const int frag_row = lane & 31, h = lane >> 5;
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+
+    // ---- fragment read bases.  A: pixel of GEMM row m (pool-window order) shifted by the tap, slot h of k-step 0.
+    unsigned abase[2][9];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = wave_m * 64 + 32 * i + frag_row;
+        if (m >= MPIX) m = 0;                                          // padding rows: any valid pixel, never stored
+        const int win = m >> 2, q = m & 3;
+        const int py = 2 * (win / (PW / 2)) + (q >> 1), px = 2 * (win % (PW / 2)) + (q & 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hp = (py + t / 3) * HWD + px + t % 3;
+            abase[i][t] = (unsigned)(hp * CKB + ((h ^ key_of(hp)) << 4));
+        }
+    }
+    unsigned bbase[NS16];                                              // B: weight row of this lane, slot of k-step s
+    {
+        const int n_l = wave_n * 64 + frag_row;
+#pragma unroll
+        for (int s = 0; s < NS16; ++s) bbase[s] = (unsigned)(BOFF + n_l * CKB + (((2 * s + h) ^ key_of(n_l)) << 4));
+    }
+
+    // ---- DMA geometry of this lane: row dl_row of a piece, 16-byte slot dl_slot
+    const int dl_row = lane / NSLOT, dl_slot = lane % NSLOT;
+    unsigned voff_b[PB];                                               // weight pieces wave + NW * k of a stage
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+        const int r = (wave + NW * k) * PIXPP + dl_row, n = r % BN, t = r / BN;
+        voff_b[k] = (unsigned)(((n * 9 + t) * a.Cin) * 2 + ((dl_slot ^ key_of(r)) << 4));
+    }
+    unsigned voff_h[HPW];                                              // halo pieces wave + NW * k
+    int hyx[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int hp = (wave + NW * k) * PIXPP + dl_row, hy = hp / HWD, hx = hp - hy * HWD;
+        voff_h[k] = (unsigned)(((hy * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_of(hp)) << 4));
+        hyx[k] = hp < HPIX && wave + NW * k < HP ? (hy | (hx << 16)) : -1;
+    }
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * 2), 0x00020000);
+
+    // ---- work: item = (patch, channel tile), channel tile fastest; a step = one K chunk of an item
+    struct Step {
+        int img, y0, x0, nt, c;
+        bool live;
+    };
+    auto step_of = [&](int u) {
+        Step d;
+        const int k = u / nch;
+        const long long item = (long long)blockIdx.x + (long long)k * G;
+        d.live = item < a.items;
+        const int it = d.live ? (int)item : 0;
+        d.c = u - k * nch;
+        d.nt = it % a.ntiles;
+        const int patch = it / a.ntiles;
+        const int tx = patch % a.tiles_x, r = patch / a.tiles_x;
+        d.x0 = tx * PW;
+        d.y0 = (r % a.tiles_y) * PH;
+        d.img = r / a.tiles_y;
+        d.img = __builtin_amdgcn_readfirstlane(d.img); d.y0 = __builtin_amdgcn_readfirstlane(d.y0);
+        d.x0 = __builtin_amdgcn_readfirstlane(d.x0); d.nt = __builtin_amdgcn_readfirstlane(d.nt);
+        d.c = __builtin_amdgcn_readfirstlane(d.c);
+        return d;
+    };
+    // halo piece k of this wave for step d into halo buffer `buf`.  The resource starts (W + 1) pixels before the image so
+    // that the scalar offset of the patch origin (y0 - 1, x0 - 1) is never negative; lanes outside the image read as zero.
+    const int a_shift = (a.W + 1) * a.Cin * 2;
+    auto dma_halo = [&](const Step &d, int k, int buf) {
+        const long long img_b = (long long)d.img * a.H * a.W * a.Cin * 2;
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(static_cast<const char *>(a.x)) + img_b - a_shift, 0,
+            d.live ? a.H * a.W * a.Cin * 2 + a_shift : 0, 0x00020000);
+        const int soff = ((d.y0 * a.W + d.x0) * a.Cin + d.c * CK) * 2;
+        const int hy = hyx[k] & 0xFFFF, hx = hyx[k] >> 16;
+        const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W;
+        if (wave + NW * k < HP)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(lds + buf * HALO1 + (wave + NW * k) * 1024), 16,
+                                                     (int)(ok ? voff_h[k] : kOOB), soff, 0, 0);
+    };
+    // the PB weight pieces of this wave for stage `st` of step d into ring slot `slot`
+    auto dma_b = [&](const Step &d, int st, int slot) {
+        const int soff = d.live ? ((d.nt * BN * 9 + st * TS) * a.Cin + d.c * CK) * 2 : 0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr)(lds + BOFF + slot * STAGE + (wave + NW * k) * 1024), 16,
+                                                     (int)voff_b[k], soff, 0, 0);
+    };
+
+    // ---- output geometry: lane holds channel (lane & 31) of tile column j; accumulator registers 4g .. 4g+3 of block i
+    //      are the four pixels of pool window wave_m * 16 + 8i + 2g + h of the patch
+    unsigned woff[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int w = wave_m * 16 + 8 * i + 2 * g + h;
+            woff[i][g] = w < WINS ? (unsigned)(((w / (PW / 2)) * Wo + w % (PW / 2)) * a.Cout * 2) : kNoStore;
+        }
+    const long long y_bytes = (long long)a.NB * Ho * Wo * a.Cout * 2;
+
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    struct Frag {
+        bf16x8 a[2], b[2];
+    };
+    // k-step s of tap `tap`; the weights of that tap are rows [tb * BN, (tb + 1) * BN) of ring slot `slot`
+    auto read_frag = [&](Frag &f, int tap, int s, int slot, int tb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[abase[i][tap] ^ (unsigned)(s << 5)], 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            f.b[j] = *reinterpret_cast<const bf16x8 *>(
+                __builtin_assume_aligned(&lds[bbase[s] + (unsigned)(slot * STAGE + (tb * BN + 32 * j) * CKB)], 16));
+    };
+    auto mfma = [&](const Frag &f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+    // all k-steps of stage `st` (TS taps), fragments read one k-step ahead of their MFMAs
+    auto compute_stage = [&](int st) {
+        constexpr int STEPS = TS * NS16;
+        const int slot = RES_B ? 0 : st % 3;
+        Frag f[3];                                             // fragments run two k-steps ahead of their MFMAs
+        read_frag(f[0], st * TS, 0, slot, 0);
+        if (STEPS > 1) read_frag(f[1], st * TS + 1 / NS16, 1 % NS16, slot, 1 / NS16);
+#pragma unroll
+        for (int q = 0; q < STEPS; ++q) {
+            if (q + 2 < STEPS) read_frag(f[(q + 2) % 3], st * TS + (q + 2) / NS16, (q + 2) % NS16, slot, (q + 2) / NS16);
+            mfma(f[q % 3]);
+        }
+    };
+    auto wg_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // BN scale / shift of the item's channels: loaded when its first step starts, pinned behind that step's first wait
+    float sc[2], sh[2];
+    auto load_bn = [&](const Step &d) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = d.nt * BN + wave_n * 64 + 32 * j + (lane & 31);
+            sc[j] = a.scale[n];
+            sh[j] = a.shift[n];
+        }
+    };
+    auto landed = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
+    };
+    auto epilogue = [&](const Step &d) {
+        const long long o_org = (((long long)d.img * Ho + (d.y0 >> 1)) * Wo + (d.x0 >> 1)) * a.Cout * 2;
+        const long long left = y_bytes - o_org;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            static_cast<char *>(a.y) + o_org, 0, (int)(left > 0x7FFFFFFFll ? 0x7FFFFFFFll : left), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = d.nt * BN + wave_n * 64 + 32 * j + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] * sc[j] + sh[j];
+                    const float t = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));       // pool first (alpha >= 0), activate once
+                    const float pooled = t > 0.f ? t : t * a.alpha;
+                    __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(pooled), o_rsrc, (int)(woff[i][g] + (unsigned)n * 2u), 0, 0);
+                }
+        }
+    };
+
+    // ---- prologue: first halo, first weight stages
+    int u = 0;
+    Step cur = step_of(0);
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) dma_halo(cur, k, 0);
+    if (RES_B) {
+        dma_b(cur, 0, 0);
+    } else {
+        dma_b(cur, 0, 0);
+        dma_b(cur, 1, 1);
+    }
+    load_bn(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    zero_acc();
+    int hbuf = 0;
+
+    while (cur.live) {
+        const Step nxt = step_of(u + 1);
+        if (u > 0 && cur.c == 0) load_bn(cur);
+        if (RES_B) {
+            // the whole next halo goes out first and lands under the 9 x NS16 k-steps of this patch
+#pragma unroll
+            for (int k = 0; k < HPW; ++k) dma_halo(nxt, k, hbuf ^ 1);
+            compute_stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stores of the previous epilogue are a whole patch old)
+            landed();
+            wg_barrier();
+        } else {
+#pragma unroll
+            for (int st = 0; st < NSC; ++st) {
+                // fetch: one halo piece of the next step, then the weights two stages ahead (ring slot last read in stage st - 1)
+                if (st < HPW) dma_halo(nxt, st, hbuf ^ 1);
+                if (st + 2 < NSC) dma_b(cur, st + 2, (st + 2) % 3);
+                else dma_b(nxt, st + 2 - NSC, (st + 2) % 3);
+                compute_stage(st);
+                // the PB newest DMAs of this wave (stage st + 2) may stay in flight; everything older - stage st + 1, the
+                // halo piece, the stores of an epilogue a stage ago - has landed once the counter is down to PB
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+                if (st == 0) landed();
+                wg_barrier();
+            }
+        }
+        if (cur.c == nch - 1) {
+            epilogue(cur);
+            zero_acc();
+        }
+        {
+            const unsigned delta = hbuf ? (unsigned)-HALO1 : (unsigned)HALO1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) abase[i][t] += delta;
+        }
+        hbuf ^= 1;
+        cur = nxt;
+        ++u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+}
+
+int num_cus_here() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return cus;
+}
+
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B>
+int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
+    a.tiles_x = a.W / PW;
+    a.tiles_y = a.H / PH;
+    a.ntiles = a.Cout / BN;
+    const long long items = (long long)a.NB * a.tiles_x * a.tiles_y * a.ntiles;
+    TY1_REQUIRE(items < (1ll << 31), "ty1_conv3x3_bf16(halo): too many work items");
+    a.items = (int)items;
+    const long long want = (long long)per_cu * num_cus_here();
+    const double px = (double)a.NB * a.H * a.W;
+    ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / 4));
+    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B>
+        <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
+    return ty1::check_launch(name);
+}
+
+}  // namespace
+
+namespace ty1 {
+
+// 1 if a halo instantiation exists for this pooled bf16 layer and it has enough work items to balance the chip
+// (then conv3x3_halo_bf16 runs it), 0 otherwise: the caller falls back to the implicit-GEMM kernel.
+int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool) {
+    if (!pool || (long long)H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return 0;
+    const long long cus = num_cus_here();
+    if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return (long long)N * (H / 16) * (W / 16) >= 8 * cus;
+    if (Cin % 64 == 0 && Cin <= 256 && Cout % 128 == 0 && H % 8 == 0 && W % 28 == 0)
+        return (long long)N * (H / 8) * (W / 28) * (Cout / 128) >= 4 * cus;
+    return 0;
+}
+
+int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
+                      int Cin, int Cout, float alpha, hipStream_t s) {
+    HaloArgs a{};
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
+    a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.alpha = alpha;
+    if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
+    return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+}
+
+}  // namespace ty1
