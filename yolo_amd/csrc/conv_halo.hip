@@ -33,7 +33,13 @@ struct HaloArgs {
     int NB, H, W, Cin, Cout;
     float alpha;
     int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
+    int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue
 };
+#ifdef TY1_DEV_STAMPS
+#define HALO_DBG(bit) ((a.dbg & (bit)) != 0)
+#else
+#define HALO_DBG(bit) false
+#endif
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to nearest even
     const __bf16 hv = (__bf16)v;
@@ -147,13 +153,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const int soff = ((d.y0 * a.W + d.x0) * a.Cin + d.c * CK) * 2;
         const int hy = hyx[k] & 0xFFFF, hx = hyx[k] >> 16;
         const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W;
-        if (wave + NW * k < HP)
+        if (wave + NW * k < HP && !HALO_DBG(1))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(lds + buf * HALO1 + (wave + NW * k) * 1024), 16,
                                                      (int)(ok ? voff_h[k] : kOOB), soff, 0, 0);
     };
     // the PB weight pieces of this wave for stage `st` of step d into ring slot `slot`
     auto dma_b = [&](const Step &d, int st, int slot) {
         const int soff = d.live ? ((d.nt * BN * 9 + st * TS) * a.Cin + d.c * CK) * 2 : 0;
+        if (HALO_DBG(2)) return;
 #pragma unroll
         for (int k = 0; k < PB; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr)(lds + BOFF + slot * STAGE + (wave + NW * k) * 1024), 16,
@@ -213,7 +220,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
             mfma(f[q % 3]);
         }
     };
-    auto wg_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto wg_barrier = [&] {
+        if (HALO_DBG(4)) return;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
 
     // BN scale / shift of the item's channels: loaded when its first step starts, pinned behind that step's first wait
     float sc[2], sh[2];
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
             }
         }
         if (cur.c == nch - 1) {
-            epilogue(cur);
+            if (!HALO_DBG(8)) epilogue(cur);
             zero_acc();
         }
         {
@@ -356,6 +366,7 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha;
+    if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
     if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
     return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
 }
