@@ -223,6 +223,20 @@ int ty1_head_activate_bwd_f32(const float *y, const float *grad_y, float *dz, in
                               int ldz, ty1_stream_t stream);
 
 /*
+ * The training tail behind the Dense GEMM in one launch: ty1_head_activate_f32, the per-image part of
+ * ty1_yolo_loss_fwd_bwd and ty1_head_activate_bwd_f32 with the head tensor and its gradient kept in LDS (one workgroup per
+ * image), then the fixed-order batch sum of the loss.  Same arithmetic and the same bits as the three calls.
+ * Replaces /root/reference/models/model_tiny_yolov1.py:14-34 (forward and autodiff) and /root/reference/yolo/yolo.py:48-107
+ * as /root/reference/train.py:59-60,94-104 runs them inside fit().
+ *   part (splits,N,ldz_part) Dense split-K partials; bias (units) or NULL; y_true (N,S,S,C+5);
+ *   y (N,S,S,C+5B) or NULL (the head tensor then never reaches HBM); dz (N,ldz) planar dL/dz, zero behind the units;
+ *   loss_per_image (N); loss (1) batch SUM.
+ */
+int ty1_train_tail_f32(const float *part, const float *bias, const float *y_true, float *y, float *dz, int N, int S,
+                       int B, int C, int ldz_part, int splits, int img_size, int ldz, float *loss_per_image, float *loss,
+                       ty1_stream_t stream);
+
+/*
  * Dense weight gradient (the only trainable layer):
  *   dwt[u][k] = sum_n dz[n][u] * x[n][k]   (u < units, k < K),   db[u] = sum_n dz[n][u]
  * Replaces the autodiff of Dense(1470): /root/reference/models/model_tiny_yolov1.py:96.

@@ -317,6 +317,47 @@ def test_yolo_loss_batch_vs_oracle():
     assert abs(la.item() + lb.item() - loss.item()) <= 1e-5 * abs(loss.item())
 
 
+@pytest.mark.parametrize('N,C,golden', [(32, 20, None), (5, 1, None), (0, 20, 'loss_c20.npz'), (0, 1, 'loss_c1.npz')])
+def test_train_tail_equals_the_three_launches(N, C, golden):
+    """ty1_train_tail_f32 (head activation + yolo_loss fwd/bwd + head Jacobian in one launch, y and dL/dy in LDS) against
+    ty1_head_activate_f32 -> ty1_yolo_loss_fwd_bwd -> ty1_head_activate_bwd_f32: the same device functions in the same
+    order, so loss, per-image loss, dz and the optional head tensor must agree bit for bit - including the NaN cells of
+    the reference-run goldens (their labels; logits chosen so that the adversarial cells keep their zero-size boxes)."""
+    rng = np.random.default_rng(11 + C)
+    units, D = 49 * (C + 10), C + 10
+    if golden:
+        g = load_golden(golden)
+        y_true = g['y_true'].astype(np.float32)
+        N = y_true.shape[0]
+    else:
+        y_true = np.zeros((N, 7, 7, C + 5), np.float32)
+        for n in range(N):
+            for _ in range(4):
+                r, c, k = rng.integers(0, 7), rng.integers(0, 7), rng.integers(0, C)
+                if y_true[n, r, c, C + 4] == 0:
+                    y_true[n, r, c, k] = 1
+                    y_true[n, r, c, C:C + 4] = rng.random(4)
+                    y_true[n, r, c, C + 4] = 1
+    splits, ldz = 6, ops.round_up(units, 4)
+    part = (3.0 * rng.standard_normal((splits, N, ldz))).astype(np.float32)
+    part[:, :, units:] = np.nan                                  # padding columns must never be read
+    if golden:                                                   # box logits far below the sigmoid's underflow: width exactly 0
+        part[:, 0, 49 * C + 98 + 2] = -200.0
+    bias = rng.standard_normal(units).astype(np.float32)
+    pd, bd, td = dev(part), dev(bias), dev(y_true)
+    y = ops.head_activate(pd, bd, 7, 2, C)
+    loss, per, grad = ops.yolo_loss_fwd_bwd(td, y, 2, C, 448)
+    dz = ops.head_activate_bwd(y, grad, ldz, 2, C)
+    y2 = torch.empty_like(y)
+    loss2, per2, dz2 = ops.train_tail(pd, bd, td, ldz, 7, 2, C, 448, y=y2)
+    loss3, per3, dz3 = ops.train_tail(pd, bd, td, ldz, 7, 2, C, 448)          # without the head tensor
+    same = lambda a, b: np.array_equal(a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32))
+    assert same(y, y2) and same(per, per2) and same(loss, loss2) and same(dz, dz2)
+    assert same(per, per3) and same(loss, loss3) and same(dz, dz3)
+    if golden:
+        assert torch.isnan(dz).any()                             # the zero-width cell did produce its NaN
+
+
 # ------------------------------------------------------------------------------- training kernels
 def test_head_backward_wgrad_adam_vs_torch():
     rng = np.random.default_rng(4)

@@ -34,6 +34,7 @@ SIGNATURES = {
     'ty1_iou_f32': [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
     'ty1_yolo_loss_fwd_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     'ty1_head_activate_bwd_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'ty1_train_tail_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     'ty1_dense_wgrad_f32': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'ty1_adam_step_f32': [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _vp],
     'ty1_prof_enable': [_i],

@@ -37,26 +37,9 @@ __global__ __launch_bounds__(256) void head_activate_kernel(const float *__restr
 __global__ __launch_bounds__(256) void head_activate_bwd_kernel(const float *__restrict__ y,
                                                                  const float *__restrict__ gy, float *__restrict__ dz,
                                                                  int N, int S, int B, int C, int ldz) {
-    const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
-    const float *yn = y + (size_t)n * units, *gn = gy + (size_t)n * units;
-    float *dn = dz + (size_t)n * ldz;
-    const int i1 = cells * C, i2 = i1 + cells * B;
-    for (int cell = threadIdx.x; cell < cells; cell += blockDim.x) {
-        float dot = 0.f;
-        for (int m = 0; m < C; ++m) dot += gn[cell * D + m] * yn[cell * D + m];
-        for (int m = 0; m < C; ++m) dn[cell * C + m] = yn[cell * D + m] * (gn[cell * D + m] - dot);
-    }
-    for (int i = threadIdx.x; i < cells * B; i += blockDim.x) {
-        const int cell = i / B, k = i - cell * B;
-        const float s = yn[cell * D + C + k];
-        dn[i1 + i] = gn[cell * D + C + k] * s * (1.f - s);
-    }
-    for (int i = threadIdx.x; i < cells * 4 * B; i += blockDim.x) {
-        const int cell = i / (4 * B), k = i - cell * (4 * B);
-        const float s = yn[cell * D + C + B + k];
-        dn[i2 + i] = gn[cell * D + C + B + k] * s * (1.f - s);
-    }
-    for (int u = units + threadIdx.x; u < ldz; u += blockDim.x) dn[u] = 0.f;
+    const int n = blockIdx.x, cells = S * S, units = cells * (C + 5 * B);
+    ty1::head_bwd_image(y + (size_t)n * units, gy + (size_t)n * units, dz + (size_t)n * ldz, cells, B, C, ldz, (int)threadIdx.x,
+                        (int)blockDim.x);
 }
 
 }  // namespace

@@ -49,4 +49,29 @@ __device__ __forceinline__ float activate_channel(const float *zc, int d, int C)
     return sigmoid_f32(zc[d]);
 }
 
+// Backward of ReshapeYOLO.call for one image: softmax Jacobian for the classes, s(1 - s) for the sigmoids; yn / gn are
+// the image's activated tensor and its gradient (cell-major, D = C + 5B per cell, global memory or LDS), dn the image's
+// planar dz row of ldz floats (zero-filled behind the units).  Thread tid of nthreads.
+__device__ __forceinline__ void head_bwd_image(const float *yn, const float *gn, float *dn, int cells, int B, int C, int ldz,
+                                               int tid, int nthreads) {
+    const int D = C + 5 * B, units = cells * D;
+    const int i1 = cells * C, i2 = i1 + cells * B;
+    for (int cell = tid; cell < cells; cell += nthreads) {
+        float dot = 0.f;
+        for (int m = 0; m < C; ++m) dot += gn[cell * D + m] * yn[cell * D + m];
+        for (int m = 0; m < C; ++m) dn[cell * C + m] = yn[cell * D + m] * (gn[cell * D + m] - dot);
+    }
+    for (int i = tid; i < cells * B; i += nthreads) {
+        const int cell = i / B, k = i - cell * B;
+        const float s = yn[cell * D + C + k];
+        dn[i1 + i] = gn[cell * D + C + k] * s * (1.f - s);
+    }
+    for (int i = tid; i < cells * 4 * B; i += nthreads) {
+        const int cell = i / (4 * B), k = i - cell * (4 * B);
+        const float s = yn[cell * D + C + B + k];
+        dn[i2 + i] = gn[cell * D + C + B + k] * s * (1.f - s);
+    }
+    for (int u = units + tid; u < ldz; u += nthreads) dn[u] = 0.f;
+}
+
 }  // namespace ty1

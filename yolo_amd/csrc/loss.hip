@@ -6,45 +6,12 @@
 // box mask carries no gradient).  Per-image sums use a fixed butterfly, the batch SUM (Q12: not a
 // mean) is a second single-block kernel with a fixed order, so results are run-to-run deterministic.
 #include "common.h"
+#include "head_math.h"
+#include "loss_math.h"
 
 #pragma clang fp contract(off)
 
 namespace {
-
-// K.max (tf.reduce_max; torch.amax in the golden generator's backend mapping): a NaN operand gives NaN
-__device__ __forceinline__ float max_nan(float a, float b) {
-    if (a != a) return a;
-    if (b != b) return b;
-    return a >= b ? a : b;
-}
-
-// d/dw of 5*MR*((sqrt(clip(img*lw, 0)) - sqrt(clip(img*w, 0))) / img)^2 as autodiff delivers it (K.sqrt clips its argument
-// at 0 first): the clip passes no gradient for w < 0; at w == 0 the square root's derivative is infinite, so the chain
-// rule gives 0 * inf = NaN even where the box is not responsible (MR == 0).
-__device__ __forceinline__ float dwh(float MR, float l, float b, float img) {
-    if (b < 0.f) return 0.f;
-    if (MR > 0.f) return 5.f * MR * (1.f - sqrtf(fmaxf(l, 0.f) / b)) / img;
-    return b == 0.f ? __builtin_nanf("") : 0.f;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// yolo/yolo.py:6-20 on one pair of boxes (float32, K.maximum(x, 0.) clamps)
-__device__ __forceinline__ float iou_f32(float pminx, float pminy, float pmaxx, float pmaxy, float tminx, float tminy,
-                                         float tmaxx, float tmaxy) {
-    float iw = fminf(pmaxx, tmaxx) - fmaxf(pminx, tminx);
-    float ih = fminf(pmaxy, tmaxy) - fmaxf(pminy, tminy);
-    iw = fmaxf(iw, 0.f);
-    ih = fmaxf(ih, 0.f);
-    const float inter = iw * ih;
-    const float pa = (pmaxx - pminx) * (pmaxy - pminy);
-    const float ta = (tmaxx - tminx) * (tmaxy - tminy);
-    return inter / (pa + ta - inter);
-}
 
 template <int B>
 __global__ __launch_bounds__(256) void yolo_loss_kernel(const float *__restrict__ y_true,
@@ -60,62 +27,9 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(const float *__restrict_
         const float *t = y_true + ((size_t)n * cells + lane) * Dt;
         const float *p = y_pred + ((size_t)n * cells + lane) * Dp;
         float *g = grad ? grad + ((size_t)n * cells + lane) * Dp : nullptr;
-        const int r = lane / S, c = lane - r * S;
-        const float fS = (float)S;
-        const float R = t[C + 4];
-        // label box -> pixels (yolo_head :42-43, X_Y_W_H_To_Min_Max)
-        const float lx = t[C + 0], ly = t[C + 1], lw = t[C + 2], lh = t[C + 3];
-        const float lxy0 = (lx + (float)c) / fS * img, lxy1 = (ly + (float)r) / fS * img;
-        const float lwp = lw * img, lhp = lh * img;
-        const float lminx = lxy0 - lwp / 2, lminy = lxy1 - lhp / 2, lmaxx = lxy0 + lwp / 2, lmaxy = lxy1 + lhp / 2;
-
-        float ious[B], px[B], py[B], pw[B], ph[B], bx[B], by[B], bw[B], bh[B];
-        float best = 0.f;
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const float *pb = p + C + B + 4 * k;
-            bx[k] = pb[0]; by[k] = pb[1]; bw[k] = pb[2]; bh[k] = pb[3];
-            px[k] = (bx[k] + (float)c) / fS * img;
-            py[k] = (by[k] + (float)r) / fS * img;
-            pw[k] = bw[k] * img;
-            ph[k] = bh[k] * img;
-            ious[k] = iou_f32(px[k] - pw[k] / 2, py[k] - ph[k] / 2, px[k] + pw[k] / 2, py[k] + ph[k] / 2, lminx, lminy,
-                              lmaxx, lmaxy);
-            // K.max :79-80 propagates a NaN IoU (0/0: zero-area label and zero-area box); `>=` below is then False for
-            // every box of the cell and none is responsible
-            best = (k == 0) ? ious[k] : max_nan(best, ious[k]);
-        }
-        // class loss :89
-        float acc = 0.f;
-        for (int m = 0; m < C; ++m) {
-            const float d = t[m] - p[m];
-            acc += R * (d * d);
-            if (g) g[m] = 2.f * R * (p[m] - t[m]);
-        }
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            const float Mk = (ious[k] >= best) ? 1.f : 0.f;          // :82 (no gradient)
-            const float MR = Mk * R;
-            const float tk = p[C + k];
-            // confidence :84-86
-            acc += 0.5f * (1.f - MR) * ((0.f - tk) * (0.f - tk)) + MR * ((1.f - tk) * (1.f - tk));
-            // box :101-102
-            const float dx = (lxy0 - px[k]) / img, dy = (lxy1 - py[k]) / img;
-            const float sw = (sqrtf(fmaxf(lwp, 0.f)) - sqrtf(fmaxf(pw[k], 0.f))) / img;
-            const float sh = (sqrtf(fmaxf(lhp, 0.f)) - sqrtf(fmaxf(ph[k], 0.f))) / img;
-            acc += 5.f * MR * (dx * dx) + 5.f * MR * (dy * dy) + 5.f * MR * (sw * sw) + 5.f * MR * (sh * sh);
-            if (g) {
-                g[C + k] = (1.f - MR) * tk - 2.f * MR * (1.f - tk);
-                float *gb = g + C + B + 4 * k;
-                gb[0] = -10.f * MR * (lx - bx[k]) / (fS * fS);
-                gb[1] = -10.f * MR * (ly - by[k]) / (fS * fS);
-                gb[2] = dwh(MR, lw, bw[k], img);
-                gb[3] = dwh(MR, lh, bh[k], img);
-            }
-        }
-        cell_loss = acc;
+        cell_loss = ty1::loss_cell<B>(t, p, g, lane, S, C, img);
     }
-    const float total = wave_sum(cell_loss);
+    const float total = ty1::wave_sum(cell_loss);
     if (lane == 0) loss_per_image[n] = total;
 }
 
@@ -130,6 +44,57 @@ __global__ __launch_bounds__(256) void sum_fixed_order_kernel(const float *__res
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// The training tail behind the Dense GEMM in one launch (ty1_train_tail_f32): ty1_head_activate_f32, ty1_yolo_loss_fwd_bwd's
+// per-image part and ty1_head_activate_bwd_f32 with the head tensor and its gradient kept in LDS.  One 1024-thread
+// workgroup per image: all sixteen waves reduce the split-K partials and activate the logits (head_math.h), wave 0 runs
+// the loss cell code (loss_math.h), all waves apply the head Jacobian and write the planar dz row.  Same functions, same
+// order of operations as the three separate kernels: same bits.
+constexpr int kTrainTailThreads = 1024;
+template <int B>
+__global__ __launch_bounds__(kTrainTailThreads) void train_tail_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                                       const float *__restrict__ y_true, float *__restrict__ y,
+                                                                       float *__restrict__ dz, int N, int S, int C, int ldz_part,
+                                                                       int splits, float img, int ldz, float *__restrict__ loss_per_image) {
+    extern __shared__ float lds[];
+    const int n = blockIdx.x, cells = S * S, D = C + 5 * B, units = cells * D;
+    float *z = lds, *yl = lds + ((units + 1) & ~1), *gl = yl + ((units + 1) & ~1), *smx = gl + ((units + 1) & ~1), *ssum = smx + 64;
+    const size_t slab = (size_t)N * ldz_part;
+    const float *pn = part + (size_t)n * ldz_part;
+    for (int t = threadIdx.x; t < units; t += kTrainTailThreads) {
+        const int cell = t / D, d = t - cell * D;
+        z[t] = ty1::reduce_unit(pn, slab, ty1::planar_unit(cell, d, cells, B, C), bias, splits);
+    }
+    __syncthreads();
+    // softmax maximum and denominator once per cell, in activate_channel's order (same bits)
+    if ((int)threadIdx.x < cells) {
+        const float *zc = z + threadIdx.x * D;
+        float mx = zc[0];
+        for (int m = 1; m < C; ++m) mx = fmaxf(mx, zc[m]);
+        float sum = 0.f;
+        for (int m = 0; m < C; ++m) sum += expf(zc[m] - mx);
+        smx[threadIdx.x] = mx;
+        ssum[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < units; t += kTrainTailThreads) {
+        const int cell = t / D, d = t - cell * D;
+        const float v = d < C ? expf(z[t] - smx[cell]) / ssum[cell] : ty1::sigmoid_f32(z[t]);
+        yl[t] = v;
+        if (y) y[(size_t)n * units + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float cell_loss = 0.f;
+        if (lane < cells)
+            cell_loss = ty1::loss_cell<B>(y_true + ((size_t)n * cells + lane) * (C + 5), yl + lane * D, gl + lane * D, lane, S, C, img);
+        const float total = ty1::wave_sum(cell_loss);
+        if (lane == 0) loss_per_image[n] = total;
+    }
+    __syncthreads();
+    ty1::head_bwd_image(yl, gl, dz + (size_t)n * ldz, cells, B, C, ldz, (int)threadIdx.x, kTrainTailThreads);
 }
 
 __global__ void yolo_head_kernel(const float *__restrict__ feats, float *__restrict__ xy, float *__restrict__ wh,
@@ -149,7 +114,7 @@ __global__ void iou_kernel(const float2 *__restrict__ pmin, const float2 *__rest
                            long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = iou_f32(pmin[i].x, pmin[i].y, pmax[i].x, pmax[i].y, tmin[i].x, tmin[i].y, tmax[i].x, tmax[i].y);
+    out[i] = ty1::iou_f32(pmin[i].x, pmin[i].y, pmax[i].x, pmax[i].y, tmin[i].x, tmin[i].y, tmax[i].x, tmax[i].y);
 }
 
 }  // namespace
@@ -179,6 +144,40 @@ extern "C" int ty1_yolo_loss_fwd_bwd(const float *y_true, const float *y_pred, i
         sum_fixed_order_kernel<<<1, 256, 0, s>>>(loss_per_image, N, loss);
     }
     return ty1::check_launch("ty1_yolo_loss_fwd_bwd(sum)");
+}
+
+extern "C" int ty1_train_tail_f32(const float *part, const float *bias, const float *y_true, float *y, float *dz, int N, int S,
+                                  int B, int C, int ldz_part, int splits, int img_size, int ldz, float *loss_per_image,
+                                  float *loss, ty1_stream_t stream) {
+    TY1_REQUIRE(N >= 0 && S > 0 && C > 0 && img_size > 0 && splits > 0, "ty1_train_tail: bad dimensions");
+    TY1_REQUIRE(S * S <= 64, "ty1_train_tail: S*S=%d exceeds one wavefront", S * S);
+    TY1_REQUIRE(B >= 1 && B <= 4, "ty1_train_tail: B=%d not in 1..4", B);
+    TY1_REQUIRE(loss, "ty1_train_tail: null loss pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) return hipMemsetAsync(loss, 0, sizeof(float), s) == hipSuccess ? 0 : ty1::fail("ty1_train_tail: memset failed");
+    const int units = S * S * (C + 5 * B);
+    TY1_REQUIRE(part && y_true && dz && loss_per_image, "ty1_train_tail: null pointer");
+    TY1_REQUIRE(ldz_part >= units && ldz >= units, "ty1_train_tail: leading dimensions (%d, %d) < units=%d", ldz_part, ldz, units);
+    const size_t lds = (size_t)(3 * ((units + 1) & ~1) + 128) * 4;
+    TY1_REQUIRE(lds <= 64 * 1024, "ty1_train_tail: C=%d needs %zu bytes of LDS (max 65536)", C, lds);
+    dim3 grid(N), block(kTrainTailThreads);
+    {
+        ty1::ProfScope prof("train_tail", s, 0.0, (double)N * 4.0 * (units * (splits + 1.0) + S * S * (C + 5) + ldz));
+#define TY1_TT(BV) train_tail_kernel<BV><<<grid, block, lds, s>>>(part, bias, y_true, y, dz, N, S, C, ldz_part, splits, (float)img_size, ldz, loss_per_image)
+        switch (B) {
+            case 1: TY1_TT(1); break;
+            case 2: TY1_TT(2); break;
+            case 3: TY1_TT(3); break;
+            default: TY1_TT(4); break;
+        }
+#undef TY1_TT
+    }
+    if (int rc = ty1::check_launch("ty1_train_tail_f32")) return rc;
+    {
+        ty1::ProfScope prof("loss_sum", s);
+        sum_fixed_order_kernel<<<1, 256, 0, s>>>(loss_per_image, N, loss);
+    }
+    return ty1::check_launch("ty1_train_tail_f32(sum)");
 }
 
 extern "C" int ty1_yolo_head_f32(const float *feats, float *xy, float *wh, int N, int S, int B, int img_size,

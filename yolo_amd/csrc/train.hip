@@ -1,5 +1,5 @@
 // Training-side kernels of the only trainable layer (Dense 'connected_0'):
-//   weight gradient dWt = dz^T . x on the exact-f32 matrix cores, bias gradient, and the Adam step.
+//   weight gradient dWt = dz^T . x on the exact-f32 matrix cores (the bias gradient rides along), and the Adam step.
 // Replaces the Keras autodiff of /root/reference/models/model_tiny_yolov1.py:96 and
 // Adam(lr=0.001) of /root/reference/train.py:59.
 #include "common.h"
@@ -13,9 +13,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The reduction dimension is so short that both MFMA operands are read straight from global memory
 // (dz row b: 32 consecutive u per half-wave, x row b: 32 consecutive k: both 128-byte segments);
 // the kernel is bound by the 73.8 MB dWt store.  Block = 4 waves (2x2), wave = 2x2 tiles of 32x32.
+// db[u] = sum_n dz[n][u]: the first column of blocks already holds every dz value of its 128 units in the A operands, so
+// its k-side-0 waves add them up on the way (even and odd images in the two lane halves, joined by one shuffle).
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restrict__ dz, const float *__restrict__ x,
-                                                          float *__restrict__ dwt, int N, int K, int units, int ldk,
-                                                          int ldz) {
+                                                          float *__restrict__ dwt, float *__restrict__ db, int N, int K,
+                                                          int units, int ldk, int ldz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wu = wave >> 1, wk = wave & 1;
     const int u0 = blockIdx.y * 128 + wu * 64, k0 = blockIdx.x * 128 + wk * 64;
@@ -29,16 +31,25 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const bool uok0 = u0 + i < units, uok1 = u0 + 32 + i < units;
     const bool kok0 = k0 + i < K, kok1 = k0 + 32 + i < K;
+    float bsum0 = 0.f, bsum1 = 0.f;
     for (int b = h; b < N + h; b += 2) {       // both half-waves run the same trip count
         const bool bok = b < N;
         const float *dzr = dz + (size_t)b * ldz + u0 + i;
         const float *xr = x + (size_t)b * K + k0 + i;
         const float a0 = (bok && uok0) ? dzr[0] : 0.f, a1 = (bok && uok1) ? dzr[32] : 0.f;
         const float b0 = (bok && kok0) ? xr[0] : 0.f, b1 = (bok && kok1) ? xr[32] : 0.f;
+        bsum0 += a0;
+        bsum1 += a1;
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (blockIdx.x == 0 && wk == 0) {
+        bsum0 += __shfl_xor(bsum0, 32, 64);
+        bsum1 += __shfl_xor(bsum1, 32, 64);
+        if (h == 0 && uok0) db[u0 + i] = bsum0;
+        if (h == 0 && uok1) db[u0 + 32 + i] = bsum1;
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -52,14 +63,6 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restric
                 if (u < units) dwt[(size_t)u * ldk + k] = acc[a][b][r];
             }
         }
-}
-
-__global__ void dense_bgrad_kernel(const float *__restrict__ dz, float *__restrict__ db, int N, int units, int ldz) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= units) return;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc += dz[(size_t)n * ldz + u];
-    db[u] = acc;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
@@ -99,17 +102,10 @@ extern "C" int ty1_dense_wgrad_f32(const float *dz, const float *x, float *dwt, 
     TY1_REQUIRE(dz && x && dwt && db, "ty1_dense_wgrad: null pointer");
     TY1_REQUIRE(ldk >= K && ldz >= units, "ty1_dense_wgrad: leading dimensions too small");
     hipStream_t s = (hipStream_t)stream;
-    {
-        ty1::ProfScope prof("dense_wgrad", s);
-        dim3 grid((K + 127) / 128, (units + 127) / 128);
-        dense_wgrad_kernel<<<grid, dim3(256), 0, s>>>(dz, x, dwt, N, K, units, ldk, ldz);
-    }
-    if (int rc = ty1::check_launch("ty1_dense_wgrad_f32")) return rc;
-    {
-        ty1::ProfScope prof("dense_bgrad", s);
-        dense_bgrad_kernel<<<dim3((units + 255) / 256), dim3(256), 0, s>>>(dz, db, N, units, ldz);
-    }
-    return ty1::check_launch("ty1_dense_wgrad_f32(bias)");
+    ty1::ProfScope prof("dense_wgrad", s);
+    dim3 grid((K + 127) / 128, (units + 127) / 128);
+    dense_wgrad_kernel<<<grid, dim3(256), 0, s>>>(dz, x, dwt, db, N, K, units, ldk, ldz);
+    return ty1::check_launch("ty1_dense_wgrad_f32");
 }
 
 extern "C" int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,

@@ -148,6 +148,7 @@ class Trainer:
         self.collective_events = None    # (start, end) CUDA events around the last all-reduce when time_collective is set
         self.time_collective = False
         self.skip_collective = False     # measurement only (bench: step time without the exchange)
+        self.fused_tail = True           # False: the three separate launches (same bits; kept for the comparison test)
 
     def gradients(self, x, y_true):
         """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
@@ -159,12 +160,17 @@ class Trainer:
         m = self.model
         N = feats.shape[0]
         ws = m.workspace(N)
-        y = m.head(feats, ws)
-        _, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size, loss_out=self.bucket.loss)
         dz = self._dz.get(N)
         if dz is None:
             dz = self._dz[N] = torch.empty((N, self.ldz), dtype=torch.float32, device=self.device)
-        ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
+        part = ops.dense_splitk(feats, m.dense_wt, m.units, part=ws['part'])
+        if self.fused_tail:
+            # head activation, loss forward / backward and head Jacobian in one launch; y and dL/dy stay in LDS
+            ops.train_tail(part, m.dense_b, y_true, self.ldz, m.S, m.B, m.C, m.img_size, dz=dz, loss_out=self.bucket.loss)
+        else:
+            y = ops.head_activate(part, m.dense_b, m.S, m.B, m.C, out=ws['y'])
+            _, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size, loss_out=self.bucket.loss)
+            ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
         ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
         return self.bucket.loss
 

@@ -343,6 +343,34 @@ def yolo_loss_fwd_bwd(y_true, y_pred, B=2, C=20, img_size=448, want_grad=True, l
     return loss, per[:N], grad
 
 
+def train_tail(part, bias, y_true, ldz, S=7, B=2, C=20, img_size=448, y=None, dz=None, loss_out=None):
+    """Dense partials (splits,N,ldz_part) [+ bias], labels (N,S,S,C+5) -> loss (1,) batch SUM, loss_per_image (N,), dz (N,ldz)
+    in ONE launch + the batch sum (head_activate + yolo_loss_fwd_bwd + head_activate_bwd, same bits).
+    y: optional (N,S,S,C+5B) tensor that also receives the head tensor; loss_out: optional (1,) slot for the loss."""
+    _chk(part, torch.float32, 'part'); _chk(y_true, torch.float32, 'y_true')
+    if part.dim() == 2:
+        part = part.unsqueeze(0)
+    splits, N, ldz_part = part.shape
+    units = S * S * (C + 5 * B)
+    if ldz_part < units or ldz < units:
+        raise ValueError(f'train_tail: leading dimensions {ldz_part} / {ldz} are smaller than the {units} Dense units')
+    if tuple(y_true.shape) != (N, S, S, C + 5):
+        raise ValueError(f'y_true {tuple(y_true.shape)} does not match N={N}, S={S}, C={C}')
+    if bias is not None:
+        _chk(bias, torch.float32, 'bias')
+        if bias.numel() < units:
+            raise ValueError(f'bias: expected {units} values, got {bias.numel()}')
+    if y is not None:
+        _chk_out(y, torch.float32, (N, S, S, C + 5 * B), 'y')
+    dev = part.device
+    dz = torch.empty((N, ldz), dtype=torch.float32, device=dev) if dz is None else _chk_out(dz, torch.float32, (N, ldz), 'dz')
+    per = torch.empty((max(N, 1),), dtype=torch.float32, device=dev)
+    loss = torch.empty((1,), dtype=torch.float32, device=dev) if loss_out is None else _chk_out(loss_out, torch.float32, (1,), 'loss_out')
+    _lib.call('ty1_train_tail_f32', part.data_ptr(), _lib.ptr(bias), y_true.data_ptr(), _lib.ptr(y), dz.data_ptr(), N, S, B, C,
+              ldz_part, splits, int(img_size), ldz, per.data_ptr(), loss.data_ptr(), _lib.current_stream())
+    return loss, per[:N], dz
+
+
 def head_activate_bwd(y, grad_y, ldz, B=2, C=20, out=None):
     _chk(y, torch.float32, 'y'); _chk(grad_y, torch.float32, 'grad_y')
     N, S = y.shape[0], y.shape[1]
