@@ -82,7 +82,8 @@ def test_conv_block_bf16_vs_oracle(N, H, cin, cout, pool, out_f32, use_ws):
 
 # batches large enough for the halo kernels (csrc/conv_halo.hip; the dispatcher takes them once a layer has at least four
 # work items per CU): weights resident (Cin = 32), streamed weights with one and with two K chunks and channel tiles
-HALO_CASES = [(44, 112, 32, 64), (80, 56, 64, 128), (40, 56, 128, 256)]
+HALO_CASES = [(44, 112, 32, 64), (80, 56, 64, 128), (40, 56, 128, 256),
+              (64, 28, 128, 256), (128, 14, 256, 512)]      # 14x14 patches: two and four K chunks, two and four channel tiles
 
 
 @pytest.mark.parametrize('N,H,cin,cout', HALO_CASES)

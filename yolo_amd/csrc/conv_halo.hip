@@ -361,6 +361,13 @@ int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool
     if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return (long long)N * (H / 16) * (W / 16) >= 8 * cus;
     if ((Cin == 64 || Cin == 128) && Cout % 128 == 0 && H % 8 == 0 && W % 28 == 0)      // one or two K chunks: what the tests cover
         return (long long)N * (H / 8) * (W / 28) * (Cout / 128) >= 4 * cus;
+    // 28x28 / 14x14 maps: 14x14 patches (196 pixels of a 256-row tile: a quarter of the rows is padding, and the kernel is
+    // still 16-25 % faster than the im2col loop) - but an item is 18-36 weight stages long, so only when the items come
+    // in whole rounds of the chip or there are many of them
+    if ((Cin == 128 || Cin == 256) && Cout % 128 == 0 && H % 14 == 0 && W % 14 == 0 && !ty1::dev_env("TY1_NO_HALO14")) {
+        const long long items = (long long)N * (H / 14) * (W / 14) * (Cout / 128);
+        return items >= 2 * cus && (items % cus == 0 || items >= 8 * cus);
+    }
     return 0;
 }
 
@@ -372,6 +379,7 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
     a.alpha = alpha;
     if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
     if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
+    if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
     return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
 }
 
