@@ -82,13 +82,14 @@ def test_conv_block_bf16_vs_oracle(N, H, cin, cout, pool, out_f32, use_ws):
 
 # batches large enough for the halo kernels (csrc/conv_halo.hip; the dispatcher takes them once a layer has at least four
 # work items per CU): weights resident (Cin = 32), streamed weights with one and with two K chunks and channel tiles
-HALO_CASES = [(44, 112, 32, 64), (80, 56, 64, 128), (40, 56, 128, 256),
-              (64, 28, 128, 256), (128, 14, 256, 512)]      # 14x14 patches: two and four K chunks, two and four channel tiles
+HALO_CASES = [(44, 112, 32, 64, True), (80, 56, 64, 128, True), (40, 56, 128, 256, True),
+              (64, 28, 128, 256, True), (128, 14, 256, 512, True),      # 14x14 patches: two and four K chunks and channel tiles
+              (126, 7, 512, 1024, False)]      # no pool, four whole 7x7 images per item; the last item holds two images
 
 
-@pytest.mark.parametrize('N,H,cin,cout', HALO_CASES)
-def test_conv_block_bf16_halo_vs_oracle(N, H, cin, cout):
-    got, ref = _case(N, H, cin, cout, True, False, seed=3 * cin + cout, use_ws=False)
+@pytest.mark.parametrize('N,H,cin,cout,pool', HALO_CASES)
+def test_conv_block_bf16_halo_vs_oracle(N, H, cin, cout, pool):
+    got, ref = _case(N, H, cin, cout, pool, False, seed=3 * cin + cout, use_ws=False)
     assert got.shape == ref.shape
     err = np.abs(got - ref)
     assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())

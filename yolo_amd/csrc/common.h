@@ -55,7 +55,7 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
 // conv_halo.hip
 int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool);
 int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
-                      int Cin, int Cout, float alpha, hipStream_t s);
+                      int Cin, int Cout, int pool, float alpha, hipStream_t s);
 
 }  // namespace ty1
 

@@ -1099,10 +1099,10 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
     }
     TY1_REQUIRE(Cin % 32 == 0, "ty1_conv3x3_bf16: Cin=%d must be 3, 16 or a multiple of 32", Cin);
     TY1_REQUIRE((2ll * H * W + 2ll * (W + 1)) * Cin * 2 < (1ll << 31), "ty1_conv3x3_bf16: one image (%dx%dx%d) is too large for 32-bit offsets", H, W, Cin);
-    // large pooled layers: input halo in LDS instead of im2col rows (conv_halo.hip); needs no workspace
+    // layers with enough whole work items: input halo in LDS instead of im2col rows (conv_halo.hip); needs no workspace
     if (!out_f32 && ty1::conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool) && !ty1::dev_env("TY1_NO_HALO")) {
         if (ws_need) return 0;
-        return ty1::conv3x3_halo_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, alpha, s);
+        return ty1::conv3x3_halo_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, s);
     }
     ConvArgs a{};
     a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w); a.scale = scale; a.shift = shift;

@@ -49,11 +49,14 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to n
 
 // CK: channels per K chunk (32 or 64).  BN: output channels per item.  PH x PW: patch (even, PH * PW <= 64 * WAVES_M).
 // RES_B: Cin == CK and Cout == BN - the whole weight tensor (9 x BN x CK) is loaded once and stays in LDS.
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B>
+// NI > 1 (layers without a pool, whole maps): an item is NI consecutive images of PH x PW = H x W pixels, each with its own
+// ring of zeros in LDS; GEMM rows in natural order (image, y, x), every accumulator is stored.
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_halo_bf16_kernel(const HaloArgs a) {
+    constexpr bool POOL = NI == 1;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int CKB = CK * 2, NSLOT = CKB / 16, NS16 = CK / 16;      // bytes, 16-byte slots, k16 steps per chunk row
-    constexpr int HWD = PW + 2, HPIX = (PH + 2) * HWD;                 // halo width, halo pixels
+    constexpr int HWD = PW + 2, HPI = (PH + 2) * HWD, HPIX = NI * HPI; // halo width, halo pixels per image, halo pixels
     constexpr int PIXPP = 1024 / CKB;                                  // pixels (rows) per 1 KiB DMA piece
     // swizzle key of row (pixel / weight row) idx: rows idx and idx + RPW start on the same bank, so the key changes every
     // RPW rows and 16 consecutive rows give 16 distinct (start bank, slot) pairs = all 64 banks for a ds_read_b128 group
@@ -65,12 +68,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     constexpr int TS = RES_B ? 9 : 1, NSC = 9 / TS, NRING = RES_B ? 1 : 3;   // taps per stage, stages per chunk, ring
     constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NW;    // bytes, pieces, pieces per wave
     constexpr int BOFF = HALO1 + HP * 1024;
-    constexpr int MPIX = PH * PW, WINS = MPIX / 4;
+    constexpr int MPIX = NI * PH * PW, WINS = MPIX / 4;
     static_assert(BN == 64 * WAVES_N, "a wave owns 64 x 64 of the tile");
-    static_assert(MPIX <= 64 * WAVES_M && MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0, "patch shape");
+    static_assert(MPIX <= 64 * WAVES_M && (!POOL || (MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0)), "patch shape");
     static_assert(BP % NW == 0, "weight pieces divide among the waves");
     static_assert(RES_B || HPW <= NSC, "one halo piece per wave and stage");
     static_assert(BOFF + NRING * STAGE <= 160 * 1024, "LDS");
+    static_assert(PH + 2 < 256 && PW + 2 < 256, "halo coordinates are packed in bytes");
     __shared__ __attribute__((aligned(1024))) char lds[BOFF + NRING * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,11 +90,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     for (int i = 0; i < 2; ++i) {
         int m = wave_m * 64 + 32 * i + frag_row;
         if (m >= MPIX) m = 0;                                          // padding rows: any valid pixel, never stored
-        const int win = m >> 2, q = m & 3;
-        const int py = 2 * (win / (PW / 2)) + (q >> 1), px = 2 * (win % (PW / 2)) + (q & 1);
+        int py, px, sub = 0;
+        if (POOL) {
+            const int win = m >> 2, q = m & 3;
+            py = 2 * (win / (PW / 2)) + (q >> 1);
+            px = 2 * (win % (PW / 2)) + (q & 1);
+        } else {
+            sub = m / (PH * PW);
+            const int rem = m - sub * (PH * PW);
+            py = rem / PW;
+            px = rem - py * PW;
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int hp = (py + t / 3) * HWD + px + t % 3;
+            const int hp = sub * HPI + (py + t / 3) * HWD + px + t % 3;
             abase[i][t] = (unsigned)(hp * CKB + ((h ^ key_of(hp)) << 4));
         }
     }
@@ -113,9 +126,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     int hyx[HPW];
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
-        const int hp = (wave + NW * k) * PIXPP + dl_row, hy = hp / HWD, hx = hp - hy * HWD;
-        voff_h[k] = (unsigned)(((hy * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_of(hp)) << 4));
-        hyx[k] = hp < HPIX && wave + NW * k < HP ? (hy | (hx << 16)) : -1;
+        const int hp = (wave + NW * k) * PIXPP + dl_row, sub = hp / HPI, hr = hp - sub * HPI, hy = hr / HWD, hx = hr - hy * HWD;
+        voff_h[k] = (unsigned)((((sub * a.H + hy) * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_of(hp)) << 4));
+        hyx[k] = hp < HPIX && wave + NW * k < HP ? (hy | (hx << 8) | (sub << 16)) : -1;
     }
     const __amdgpu_buffer_rsrc_t b_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * 2), 0x00020000);
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const int tx = patch % a.tiles_x, r = patch / a.tiles_x;
         d.x0 = tx * PW;
         d.y0 = (r % a.tiles_y) * PH;
-        d.img = r / a.tiles_y;
+        d.img = (r / a.tiles_y) * NI;
         d.img = __builtin_amdgcn_readfirstlane(d.img); d.y0 = __builtin_amdgcn_readfirstlane(d.y0);
         d.x0 = __builtin_amdgcn_readfirstlane(d.x0); d.nt = __builtin_amdgcn_readfirstlane(d.nt);
         d.c = __builtin_amdgcn_readfirstlane(d.c);
@@ -150,10 +163,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const long long img_b = (long long)d.img * a.H * a.W * a.Cin * 2;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(static_cast<const char *>(a.x)) + img_b - a_shift, 0,
-            d.live ? a.H * a.W * a.Cin * 2 + a_shift : 0, 0x00020000);
+            d.live ? NI * a.H * a.W * a.Cin * 2 + a_shift : 0, 0x00020000);
         const int soff = ((d.y0 * a.W + d.x0) * a.Cin + d.c * CK) * 2;
-        const int hy = hyx[k] & 0xFFFF, hx = hyx[k] >> 16;
-        const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W;
+        const int hy = hyx[k] & 0xFF, hx = (hyx[k] >> 8) & 0xFF, sub = hyx[k] >> 16;
+        const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W &&
+                        d.img + sub < a.NB;
         if (wave + NW * k < HP && !HALO_DBG(1))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(lds + buf * HALO1 + (wave + NW * k) * 1024), 16,
                                                      (int)(ok ? voff_h[k] : kOOB), soff, 0, 0);
@@ -241,6 +255,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
     };
     auto epilogue = [&](const Step &d) {
+        if constexpr (!POOL) {
+            // rows of the item are consecutive rows of the output; the resource ends behind the last image that exists,
+            // so padding rows and images past the batch are dropped by the range check
+            const int imgs = a.NB - d.img < NI ? a.NB - d.img : NI;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                static_cast<char *>(a.y) + (long long)d.img * (PH * PW) * a.Cout * 2, 0, imgs * (PH * PW) * a.Cout * 2, 0x00020000);
+            const unsigned row_b = (unsigned)a.Cout * 2u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned vb = (unsigned)(wave_m * 64 + 4 * h) * row_b + (unsigned)(d.nt * BN + wave_n * 64 + 32 * j + (lane & 31)) * 2u;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float t = acc[i][j][r] * sc[j] + sh[j];
+                        t = t > 0.f ? t : t * a.alpha;
+                        __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(t), o_rsrc, (int)vb,
+                                                              (32 * i + (r & 3) + 8 * (r >> 2)) * (int)row_b, 0);
+                    }
+            }
+            return;
+        }
         const long long o_org = (((long long)d.img * Ho + (d.y0 >> 1)) * Wo + (d.x0 >> 1)) * a.Cout * 2;
         const long long left = y_bytes - o_org;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -333,18 +369,18 @@ int num_cus_here() {       // cached per device id (one process may drive severa
     return cus;
 }
 
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B>
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1>
 int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     a.tiles_x = a.W / PW;
     a.tiles_y = a.H / PH;
     a.ntiles = a.Cout / BN;
-    const long long items = (long long)a.NB * a.tiles_x * a.tiles_y * a.ntiles;
+    const long long items = (long long)((a.NB + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.ntiles;
     TY1_REQUIRE(items < (1ll << 31), "ty1_conv3x3_bf16(halo): too many work items");
     a.items = (int)items;
     const long long want = (long long)per_cu * num_cus_here();
     const double px = (double)a.NB * a.H * a.W;
-    ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / 4));
-    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B>
+    ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
+    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI>
         <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
     return ty1::check_launch(name);
 }
@@ -356,8 +392,17 @@ namespace ty1 {
 // 1 if a halo instantiation exists for this pooled bf16 layer and it has enough work items to balance the chip
 // (then conv3x3_halo_bf16 runs it), 0 otherwise: the caller falls back to the implicit-GEMM kernel.
 int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool) {
-    if (!pool || (long long)H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return 0;
+    if ((long long)4 * H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return 0;
     const long long cus = num_cus_here();
+    if (!pool) {
+        // 7x7 maps without a pool, four whole images per item: one item is Cin / 64 x 9 weight stages long, so only when
+        // the items come in whole rounds of the chip (7x7x512->1024 at 128 images: 256 items)
+        if (H == 7 && W == 7 && Cin % 64 == 0 && Cin <= 512 && Cout % 128 == 0 && !ty1::dev_env("TY1_NO_HALO7")) {
+            const long long items = (long long)((N + 3) / 4) * (Cout / 128);
+            return items >= cus && items % cus == 0;
+        }
+        return 0;
+    }
     if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return (long long)N * (H / 16) * (W / 16) >= 8 * cus;
     if ((Cin == 64 || Cin == 128) && Cout % 128 == 0 && H % 8 == 0 && W % 28 == 0)      // one or two K chunks: what the tests cover
         return (long long)N * (H / 8) * (W / 28) * (Cout / 128) >= 4 * cus;
@@ -372,12 +417,13 @@ int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool
 }
 
 int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
-                      int Cin, int Cout, float alpha, hipStream_t s) {
+                      int Cin, int Cout, int pool, float alpha, hipStream_t s) {
     HaloArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha;
     if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
+    if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
     if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
     if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
     return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
