@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     constexpr int HP = (HPIX + PIXPP - 1) / PIXPP;                     // halo pieces
     constexpr int HPW = (HP + NW - 1) / NW;                            // ... per wave
     constexpr int HALO1 = HP * 1024;                                   // byte distance of the two halo buffers
-    constexpr int TS = RES_B ? 9 : 1, NSC = 9 / TS, NRING = RES_B ? 1 : 3;   // taps per stage, stages per chunk, ring
+    constexpr int TS = RES_B ? 9 : 1, NSC = 9 / TS, NRING = RES_B ? 1 : 4;   // taps per stage, stages per chunk, ring
     constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NW;    // bytes, pieces, pieces per wave
     constexpr int BOFF = HALO1 + HP * 1024;
     constexpr int MPIX = NI * PH * PW, WINS = MPIX / 4;
@@ -239,6 +239,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         if (HALO_DBG(4)) return;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+    // ---- streamed weights: the k-steps of a step form ONE stream - fragments are read two k-steps ahead of their MFMAs
+    //      ACROSS the stage barriers (and across the step boundary), so no stage starts with an exposed LDS round trip.
+    //      For that a stage must be published one barrier earlier than it is read: the weights are fetched three stages
+    //      ahead into a ring of four, and the barrier that ends a stage waits only for the reads older than the eight
+    //      (two k-steps) that already belong to the next stage.
+    constexpr int Q = NSC * NS16;
+    static_assert(RES_B || Q % 3 == 0, "the fragment ring keeps its phase from step to step");
+    Frag fr[3];
+    int gs = 0;                                 // stages so far: stage g of this workgroup lives in ring slot g & 3
+    auto read_stream = [&](Frag &f, int tap, int s, unsigned boff, unsigned hd) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[(abase[i][tap] + hd) ^ (unsigned)(s << 5)], 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            f.b[j] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[bbase[s] + boff + (unsigned)(32 * j * CKB)], 16));
+    };
+    auto stage_barrier = [&] {
+        if (HALO_DBG(4)) return;
+        asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+    };
 
     // BN scale / shift of the item's channels: loaded when its first step starts, pinned behind that step's first wait
     float sc[2], sh[2];
@@ -303,17 +324,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     Step cur = step_of(0);
 #pragma unroll
     for (int k = 0; k < HPW; ++k) dma_halo(cur, k, 0);
-    if (RES_B) {
-        dma_b(cur, 0, 0);
-    } else {
-        dma_b(cur, 0, 0);
+    dma_b(cur, 0, 0);
+    if (!RES_B) {
         dma_b(cur, 1, 1);
+        dma_b(cur, 2, 2);
     }
     load_bn(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
     zero_acc();
     int hbuf = 0;
+    if (!RES_B) {
+        read_stream(fr[0], 0, 0, 0u, 0u);
+        read_stream(fr[1], 1 / NS16, 1 % NS16, 0u, 0u);
+    }
 
     while (cur.live) {
         const Step nxt = step_of(u + 1);
@@ -327,18 +351,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
             landed();
             wg_barrier();
         } else {
+            const unsigned hd_next = hbuf ? (unsigned)-HALO1 : (unsigned)HALO1;     // the other halo buffer, relative to abase
 #pragma unroll
             for (int st = 0; st < NSC; ++st) {
-                // fetch: one halo piece of the next step, then the weights two stages ahead (ring slot last read in stage st - 1)
+                // fetch: one halo piece of the next step, then the weights three stages ahead (ring slot last read in stage st - 1)
                 if (st < HPW) dma_halo(nxt, st, hbuf ^ 1);
-                if (st + 2 < NSC) dma_b(cur, st + 2, (st + 2) % 3);
-                else dma_b(nxt, st + 2 - NSC, (st + 2) % 3);
-                compute_stage(st);
-                // the PB newest DMAs of this wave (stage st + 2) may stay in flight; everything older - stage st + 1, the
+                if (st + 3 < NSC) dma_b(cur, st + 3, (gs + 3) & 3);
+                else dma_b(nxt, st + 3 - NSC, (gs + 3) & 3);
+                const unsigned boff_cur = (unsigned)((gs & 3) * STAGE), boff_nxt = (unsigned)(((gs + 1) & 3) * STAGE);
+#pragma unroll
+                for (int ks = 0; ks < NS16; ++ks) {
+                    const int q = st * NS16 + ks, q2 = q + 2, st2 = q2 / NS16, s2 = q2 % NS16;
+                    if (q2 < Q) read_stream(fr[q2 % 3], st2, s2, st2 == st ? boff_cur : boff_nxt, 0u);
+                    else read_stream(fr[q2 % 3], st2 - NSC, s2, boff_nxt, hd_next);      // first k-steps of the next step
+                    mfma(fr[q % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the PB newest DMAs of this wave (stage st + 3) may stay in flight; everything older - stage st + 2, the
                 // halo piece, the stores of an epilogue a stage ago - has landed once the counter is down to PB
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
                 if (st == 0) landed();
-                wg_barrier();
+                stage_barrier();
+                ++gs;
             }
         }
         if (cur.c == nch - 1) {
