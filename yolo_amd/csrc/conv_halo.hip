@@ -1,19 +1,22 @@
-// Pooled 3x3 conv + folded BN + LeakyReLU blocks of the bf16 network on an LDS-resident input halo
-// (v_mfma_f32_32x32x16_bf16; /root/reference/models/model_tiny_yolov1.py:52-76, the blocks with Cin = 32 ... 128).
+// 3x3 conv + folded BN + LeakyReLU (+ 2x2 max-pool) blocks of the bf16 network on an LDS-resident input halo
+// (v_mfma_f32_32x32x16_bf16; /root/reference/models/model_tiny_yolov1.py:52-84, the blocks with Cin = 32 ... 512).
 //
 // Why a second kernel next to conv_persist_kernel (conv_gemm.hip): that loop fetches a 128-byte row of A per output
 // pixel, tap and K chunk - the im2col matrix, every activation nine times - and in bf16 the fetch, not the matrix pipe,
 // bounds it: per 16 MFMAs (512 matrix cycles) a wave issues 8 LDS-DMA instructions at 60-185 cycles each.
-// Here a workgroup owns a PH x PW patch of pre-pool pixels (GEMM rows in pool-window order, as there) and all of Cin:
+// Here a workgroup owns a PH x PW patch of pre-pool pixels (GEMM rows in pool-window order, as there) - or, for a layer
+// without a pool, NI whole images - and all of Cin:
 //   * the (PH+2) x (PW+2) halo of a 64-byte or 128-byte K chunk is moved to LDS ONCE (LDS-DMA, zeros outside the image)
 //     and serves all nine taps: a tap is a constant shift of the fragment address;
-//   * the weights stream through a ring of three stages (one tap x BN channels x chunk), fetched two stages ahead
-//     (counted vmcnt, raw s_barrier), or - when all of them fit (Cin = 32: 36 KB) - are loaded once and stay;
+//   * the weights stream through a ring of four stages (one tap x BN channels x chunk), fetched three stages ahead
+//     (counted vmcnt, raw s_barrier; fragments are read two k-steps ahead of their MFMAs across the stage barriers), or
+//     - when all of them fit (Cin = 32: 36 KB) - are loaded once and stay;
 //   * the halo of the next chunk / next patch lands in the other halo buffer while this one multiplies.
 // LDS-DMA bytes per MFMA drop from 512 to 160-270.  Bank conflicts: a pixel's (a weight row's) 16-byte K slots are
 // XOR-swizzled with the low bits of its index on the source side of the DMA; a fragment read is
 // base(lane, tap) ^ (k-step << 5) (+ immediate); switching halo buffers adds +-(buffer size) to the 18 bases.
 // Epilogue as in conv_persist_kernel: BN, 2x2 max over four accumulator registers, LeakyReLU once, bf16 store.
+// Instantiations and what the dispatcher requires of a layer: conv3x3_halo_bf16_supported() at the end of this file.
 #include "common.h"
 
 #include <atomic>
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
     };
-    // all k-steps of stage `st` (TS taps), fragments read one k-step ahead of their MFMAs
+    // (resident weights) all k-steps of a patch, fragments read two k-steps ahead of their MFMAs
     auto compute_stage = [&](int st) {
         constexpr int STEPS = TS * NS16;
         const int slot = RES_B ? 0 : st % 3;
