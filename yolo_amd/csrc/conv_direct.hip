@@ -231,6 +231,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 // byte than the f32 kernel this one is bound by its HBM traffic (155 MB at batch 64) and the LDS path.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// n / d for n < 2^31 by multiply-high and shift (round-up method)
+struct FastDivU {
+    unsigned M, l;
+};
+FastDivU make_fastdiv_u(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    return FastDivU{(unsigned)(((1ull << (32 + l)) / d) + 1ull - (1ull << 32)), l};
+}
+__device__ __forceinline__ unsigned fdiv_u(unsigned n, FastDivU f) { return (__umulhi(n, f.M) + n) >> f.l; }
 constexpr int BPX = 32;                                      // bytes per LDS pixel (16 bf16)
 constexpr int BRS = (TW + 2) * BPX + 16;                     // bytes per LDS halo row
 constexpr int BST_ITEMS = (TH + 2) * (TW + 2) * 2;           // 16-byte pieces of one halo
@@ -245,7 +255,8 @@ template <bool POOL, int NT>
 __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned short *__restrict__ x, const unsigned short *__restrict__ w,
                                                                const float *__restrict__ scale, const float *__restrict__ shift,
                                                                unsigned short *__restrict__ y, int NB, int H, int W, int Cout,
-                                                               float alpha, int tiles_x, int tiles_y, int patches) {
+                                                               float alpha, int tiles_x, int tiles_y, int patches,
+                                                               FastDivU d_tx, FastDivU d_ty) {
     __shared__ __attribute__((aligned(16))) unsigned char tile[2][(TH + 2) * BRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -279,18 +290,23 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
         lds_off[k] = i < BST_ITEMS ? rr * BRS + pp * BPX + half * 16 : -1;
         st_off[k] = (unsigned)((rr * W + pp) * (CIN * 2) + half * 16);
     }
+    // (a patch is only 18 MFMAs per wave: the scalar and vector bookkeeping around them is what this kernel's time is made
+    //  of - 209 scalar + 128 vector instructions per patch before round 2c, most of them two integer divisions per decode,
+    //  two decodes per patch and an output descriptor per epilogue piece; now magic-number division, one decode per patch
+    //  carried over to the next iteration, one descriptor per patch, and no bounds tests for patches inside the image)
     auto decode = [&](int p, int &n, int &y0, int &x0) {
         p = __builtin_amdgcn_readfirstlane(p);
-        const int tx = p % tiles_x;
-        const int r = p / tiles_x;
-        const int ty = r % tiles_y;
-        n = __builtin_amdgcn_readfirstlane(r / tiles_y);
-        y0 = __builtin_amdgcn_readfirstlane(ty * TH);
-        x0 = __builtin_amdgcn_readfirstlane(tx * TW);
+        const unsigned r = fdiv_u((unsigned)p, d_tx), tx = (unsigned)p - r * (unsigned)tiles_x;
+        const unsigned nn = fdiv_u(r, d_ty), ty = r - nn * (unsigned)tiles_y;
+        n = __builtin_amdgcn_readfirstlane((int)nn);
+        y0 = __builtin_amdgcn_readfirstlane((int)ty * TH);
+        x0 = __builtin_amdgcn_readfirstlane((int)tx * TW);
     };
+    int fn = 0, fy0 = 0, fx0 = 0;                      // patch of the last fetch()
     auto fetch = [&](int p) {
         int n, y0, x0;
-        decode(p, n, y0, x0);
+        decode(p < patches ? p : 0, n, y0, x0);
+        fn = n; fy0 = y0; fx0 = x0;
         const bool live = p < patches;
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short *>(x) + (live ? (long long)n * H * W * CIN : 0ll), 0, live ? H * W * CIN * 2 : 0, 0x00020000);
@@ -317,15 +333,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
     const unsigned out_lane = POOL ? (unsigned)wave * row_b + (unsigned)h * px_b + (unsigned)col * 2u
                                    : (unsigned)(2 * wave) * row_b + (unsigned)(2 * h) * px_b + (unsigned)col * 2u;
     const long long y_total = (long long)NB * Ho * Wo * Cout;
-    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], int n, int y0, int x0) {
-        const int u = idx >> 2, gq = idx & 3;
+    // output descriptor and bounds of the patch whose epilogue is in flight (set once per patch)
+    __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, 0, 0x00020000);
+    int rows_left = 0, cols_left = 0;
+    bool prev_full = true;
+    auto set_prev = [&](int n, int y0, int x0) {
         const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
-        const long long o_org = n < 0 ? 0ll : (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
-        const long long o_left = n < 0 ? 0ll : (y_total - o_org) * 2;
-        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
-        const int rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
-        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+        const long long o_org = (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
+        const long long o_left = (y_total - o_org) * 2;
+        o_rsrc = __builtin_amdgcn_make_buffer_rsrc(y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
+        cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+        prev_full = y0 + TH <= H && x0 + TW <= W;
+    };
+    auto epi_piece = [&](auto full_c, int idx, const f32x16 (&acc)[2][NT]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int u = idx >> 2, gq = idx & 3;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float z[4];
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
             if (POOL) {
                 const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
                 const float v = m > 0.f ? m : m * alpha;
-                const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
+                const bool ok = FULL || (0 < rows_left && 8 * u + 2 * gq < cols_left);
                 const unsigned off = ok ? out_lane + (unsigned)(8 * u + 2 * gq) * px_b + 64u * nt : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
             } else {
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
                 for (int r = 0; r < 4; ++r) {
                     const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
                     const int dy = r >> 1, dx = 2 * (8 * u + 2 * gq) + (r & 1);
-                    const bool ok = dy < rows_left && dx < cols_left;
+                    const bool ok = FULL || (dy < rows_left && dx < cols_left);
                     const unsigned off = ok ? out_lane + (unsigned)dy * row_b + (unsigned)dx * px_b + 64u * nt : kOOB;
                     __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(v), o_rsrc, (int)off, 0, 0);
                 }
@@ -351,16 +374,15 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
     };
 
     f32x16 acc[2][NT], prev[2][NT];
-    int pn = -1, py0 = 0, px0 = 0;
     int p = blockIdx.x;
     fetch(p);
+    int n = fn, y0 = fy0, x0 = fx0;                    // the current patch (decoded by its fetch)
     store(0);
     __syncthreads();
     int buf = 0;
+    // (before the first patch there is no epilogue in flight: the descriptor above has zero bytes and drops the stores)
     for (; p < patches; p += gridDim.x) {
         fetch(p + gridDim.x);
-        int n, y0, x0;
-        decode(p, n, y0, x0);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -368,18 +390,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
         const unsigned char *tl = tile[buf];
+        auto taps = [&](auto full_c) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * BRS + (t % 3) * BPX;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base0 + toff], 16));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base1 + toff], 16));
+            for (int t = 0; t < 9; ++t) {
+                const int toff = (t / 3) * BRS + (t % 3) * BPX;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base0 + toff], 16));
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&tl[base1 + toff], 16));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[nt][t], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[nt][t], acc[1][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[nt][t], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wreg[nt][t], acc[1][nt], 0, 0, 0);
+                }
+                if (t < 8) epi_piece(full_c, t, prev);           // epilogue of the previous patch, one piece per tap
             }
-            if (t < 8) epi_piece(t, prev, pn, py0, px0);     // epilogue of the previous patch, one piece per tap
-        }
+        };
+        if (prev_full) taps(std::true_type{});
+        else taps(std::false_type{});
         store(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -387,10 +413,11 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(const unsigned sh
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) prev[u][nt] = acc[u][nt];
-        pn = n; py0 = y0; px0 = x0;
+        set_prev(n, y0, x0);
+        n = fn; y0 = fy0; x0 = fx0;
     }
 #pragma unroll
-    for (int idx = 0; idx < 8; ++idx) epi_piece(idx, prev, pn, py0, px0);
+    for (int idx = 0; idx < 8; ++idx) epi_piece(std::false_type{}, idx, prev);
 }
 
 
@@ -785,7 +812,8 @@ int conv3x3_c16_direct_bf16(const void *x, const void *w, const float *scale, co
         static const int per_cu = resident_blocks(conv3x3_c16_bf16_kernel<PL, NTV>, 4, "TY1_C16B_BLOCKS");            \
         const long long want = (long long)per_cu * cu_count();                                                        \
         conv3x3_c16_bf16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(     \
-            xb, wb, scale, shift, yb, N, H, W, Cout, alpha, tiles_x, tiles_y, P);                                     \
+            xb, wb, scale, shift, yb, N, H, W, Cout, alpha, tiles_x, tiles_y, P, make_fastdiv_u((unsigned)tiles_x),  \
+            make_fastdiv_u((unsigned)tiles_y));                                                                       \
     } while (0)
     if (Cout == 32) {
         if (pool) TY1_C16B(true, 1); else TY1_C16B(false, 1);
