@@ -25,6 +25,17 @@
 
 namespace {
 
+// n / d for n < 2^31 by multiply-high and shift (round-up method)
+struct FastDivU {
+    unsigned M, l;
+};
+FastDivU make_fastdiv_u(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    return FastDivU{(unsigned)(((1ull << (32 + l)) / d) + 1ull - (1ull << 32)), l};
+}
+__device__ __forceinline__ unsigned fdiv_u(unsigned n, FastDivU f) { return (__umulhi(n, f.M) + n) >> f.l; }
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TH = 8, TW = 32;              // patch of pre-pool pixels per pipeline step
@@ -38,7 +49,7 @@ template <bool POOL, int NT>
 __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                           float *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
-                                                          int tiles_x, int tiles_y, int patches) {
+                                                          int tiles_x, int tiles_y, int patches, FastDivU d_tx, FastDivU d_ty) {
     __shared__ __attribute__((aligned(16))) float tile[2][(TH + 2) * RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, h = lane >> 5;
@@ -79,12 +90,11 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     }
     auto decode = [&](int p, int &n, int &y0, int &x0) {
         p = __builtin_amdgcn_readfirstlane(p);               // block-uniform: keeps the resource words in SGPRs
-        const int tx = p % tiles_x;
-        const int r = p / tiles_x;
-        const int ty = r % tiles_y;
-        n = __builtin_amdgcn_readfirstlane(r / tiles_y);
-        y0 = __builtin_amdgcn_readfirstlane(ty * TH);
-        x0 = __builtin_amdgcn_readfirstlane(tx * TW);
+        const unsigned r = fdiv_u((unsigned)p, d_tx), tx = (unsigned)p - r * (unsigned)tiles_x;
+        const unsigned nn = fdiv_u(r, d_ty), ty = r - nn * (unsigned)tiles_y;
+        n = __builtin_amdgcn_readfirstlane((int)nn);
+        y0 = __builtin_amdgcn_readfirstlane((int)ty * TH);
+        x0 = __builtin_amdgcn_readfirstlane((int)tx * TW);
     };
     auto fetch = [&](int p) {
         int n, y0, x0;
@@ -231,16 +241,6 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 // byte than the f32 kernel this one is bound by its HBM traffic (155 MB at batch 64) and the LDS path.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// n / d for n < 2^31 by multiply-high and shift (round-up method)
-struct FastDivU {
-    unsigned M, l;
-};
-FastDivU make_fastdiv_u(unsigned d) {
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    return FastDivU{(unsigned)(((1ull << (32 + l)) / d) + 1ull - (1ull << 32)), l};
-}
-__device__ __forceinline__ unsigned fdiv_u(unsigned n, FastDivU f) { return (__umulhi(n, f.M) + n) >> f.l; }
 constexpr int BPX = 32;                                      // bytes per LDS pixel (16 bf16)
 constexpr int BRS = (TW + 2) * BPX + 16;                     // bytes per LDS halo row
 constexpr int BST_ITEMS = (TH + 2) * (TW + 2) * 2;           // 16-byte pieces of one halo
@@ -442,7 +442,8 @@ template <bool POOL, int NT, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
                                                           void *__restrict__ y, int NB, int H, int W, int Cout, float alpha,
-                                                          int tiles_x, int tiles_y, int patches, long long *stamp, int dbg) {
+                                                          int tiles_x, int tiles_y, int patches, long long *stamp, int dbg,
+                                                          FastDivU d_tx, FastDivU d_ty) {
     // developer knock-outs (dev build only; same instruction stream, no memory traffic): 1 drop the output stores, 2 drop the halo fetch
 #ifdef TY1_DEV_STAMPS
 #define C3_DBG(bit) ((dbg & (bit)) != 0)
@@ -509,12 +510,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     const int c_g = lane < C3_V4 ? 4 * lane - 4 : -0x40000000;      // float index in the image row for x0 = 0 (a dead lane never passes the border test)
     typedef __attribute__((address_space(3))) void *lds_ptr;
     auto decode = [&](int p, int &n, int &y0, int &x0) {
-        const int tx = p % tiles_x;
-        const int r = p / tiles_x;
-        const int ty = r % tiles_y;
-        n = r / tiles_y;
-        y0 = ty * C3_TH;
-        x0 = tx * C3_TW;
+        const unsigned r = fdiv_u((unsigned)p, d_tx), tx = (unsigned)p - r * (unsigned)tiles_x;
+        const unsigned nn = fdiv_u(r, d_ty), ty = r - nn * (unsigned)tiles_y;
+        n = (int)nn;
+        y0 = (int)ty * C3_TH;
+        x0 = (int)tx * C3_TW;
     };
     constexpr unsigned kOOB = 0xFFFFFFFFu;
     auto fetch = [&](int p, int buf) {
@@ -783,7 +783,8 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
         static const int per_cu = resident_blocks(conv3x3_c16_kernel<PL, NTV>, 2, "TY1_C16_BLOCKS");                  \
         const long long want = (long long)per_cu * cu_count();                                                        \
         conv3x3_c16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(          \
-            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P);                                        \
+            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, make_fastdiv_u((unsigned)tiles_x),      \
+            make_fastdiv_u((unsigned)tiles_y));                                                                       \
     } while (0)
     if (Cout == 32) {
         if (pool) TY1_C16(true, 1); else TY1_C16(false, 1);
@@ -842,7 +843,8 @@ int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, co
         const long long want = (long long)per_cu * cu_count();                                                        \
         const long long nblk = patches < want ? patches : want;                                                       \
         conv3x3_c3p_kernel<PL, NTV, OB><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                   \
-            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr, dbg); \
+            x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr, dbg, \
+            make_fastdiv_u((unsigned)tiles_x), make_fastdiv_u((unsigned)tiles_y));                                   \
     } while (0)
 #define TY1_C3P_NT(PL, OB)                                                                                            \
     do {                                                                                                              \
