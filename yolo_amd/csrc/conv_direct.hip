@@ -129,16 +129,24 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     const unsigned out_lane = POOL ? (unsigned)wave * row_b + (unsigned)h * px_b + (unsigned)col * 4u
                                    : (unsigned)(2 * wave) * row_b + (unsigned)(2 * h) * px_b + (unsigned)col * 4u;
     const long long y_total = (long long)NB * Ho * Wo * Cout;
-    // piece idx = 4u + gq of patch (n, y0, x0); n < 0: nothing is stored
-    auto epi_piece = [&](int idx, const f32x16 (&acc)[2][NT], int n, int y0, int x0) {
-        const int u = idx >> 2, gq = idx & 3;
+    // output descriptor and bounds of the patch whose epilogue is being issued: set once per patch (before the first patch
+    // the descriptor has zero bytes and drops the stores); a patch inside the image needs no per-store test
+    __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(y, 0, 0, 0x00020000);
+    int rows_left = 0, cols_left = 0;
+    bool out_full = true;
+    auto set_out = [&](int n, int y0, int x0) {
         const int oy0 = POOL ? y0 >> 1 : y0, ox0 = POOL ? x0 >> 1 : x0;
-        const long long o_org = n < 0 ? 0ll : (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
-        const long long o_left = n < 0 ? 0ll : (y_total - o_org) * 4;
-        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
-        const int rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
-        const int cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+        const long long o_org = (((long long)n * Ho + oy0) * Wo + ox0) * Cout;
+        const long long o_left = (y_total - o_org) * 4;
+        o_rsrc = __builtin_amdgcn_make_buffer_rsrc(y + o_org, 0, (int)(o_left > 0xFFFFFFFFll ? 0xFFFFFFFFll : o_left), 0x00020000);
+        rows_left = Ho - oy0 - (POOL ? 1 : 2) * wave;
+        cols_left = Wo - ox0 - (POOL ? 1 : 2) * h;
+        out_full = y0 + TH <= H && x0 + TW <= W;
+    };
+    // piece idx = 4u + gq
+    auto epi_piece = [&](auto full_c, int idx, const f32x16 (&acc)[2][NT]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int u = idx >> 2, gq = idx & 3;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float z[4];
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
                 // LeakyReLU with alpha >= 0 is non-decreasing: pool first, activate once (same bits)
                 const float m = fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3]));
                 const float v = m > 0.f ? m : m * alpha;
-                const bool ok = 0 < rows_left && 8 * u + 2 * gq < cols_left;
+                const bool ok = FULL || (0 < rows_left && 8 * u + 2 * gq < cols_left);
                 const unsigned off = ok ? out_lane + (unsigned)(8 * u + 2 * gq) * px_b + 128u * nt : kOOB;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
             } else {
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
                 for (int r = 0; r < 4; ++r) {
                     const float v = z[r] > 0.f ? z[r] : z[r] * alpha;
                     const int dy = r >> 1, dx = 2 * (8 * u + 2 * gq) + (r & 1);
-                    const bool ok = dy < rows_left && dx < cols_left;
+                    const bool ok = FULL || (dy < rows_left && dx < cols_left);
                     const unsigned off = ok ? out_lane + (unsigned)dy * row_b + (unsigned)dx * px_b + 128u * nt : kOOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), o_rsrc, (int)off, 0, 0);
                 }
@@ -168,7 +176,6 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
     // then issued between the MFMAs of the NEXT patch (one piece per tap) instead of after its own.
     constexpr bool PIPE = NT == 1;
     f32x16 acc[2][NT], prev[2][PIPE ? NT : 1];
-    int pn = -1, py0 = 0, px0 = 0;
 
     int p = blockIdx.x;
     fetch(p);
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
         const float *tl = tile[buf];
+        auto taps = [&](auto full_c) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int toff = (t / 3) * RS + (t % 3) * CS;   // halo origin is (y0-1, x0-1): tap (dy,dx) = (t/3-1, t%3-1)
@@ -207,13 +215,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
                 }
             }
             if constexpr (PIPE) {
-                if (t < 8) epi_piece(t, prev, pn, py0, px0);
+                if (t < 8) epi_piece(full_c, t, prev);
             }
         }
+        };
+        if (PIPE && !out_full) taps(std::false_type{});
+        else taps(std::true_type{});
         store(buf ^ 1);                                     // that buffer was last read before the previous barrier
         if constexpr (!PIPE) {
+            set_out(n, y0, x0);
+            if (out_full) {
 #pragma unroll
-            for (int idx = 0; idx < 8; ++idx) epi_piece(idx, acc, n, y0, x0);
+                for (int idx = 0; idx < 8; ++idx) epi_piece(std::true_type{}, idx, acc);
+            } else {
+#pragma unroll
+                for (int idx = 0; idx < 8; ++idx) epi_piece(std::false_type{}, idx, acc);
+            }
         }
         __syncthreads();
         buf ^= 1;
@@ -222,12 +239,12 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const float *__restric
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) prev[u][nt] = acc[u][nt];
-            pn = n; py0 = y0; px0 = x0;
+            set_out(n, y0, x0);
         }
     }
     if constexpr (PIPE) {
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) epi_piece(idx, prev, pn, py0, px0);
+        for (int idx = 0; idx < 8; ++idx) epi_piece(std::false_type{}, idx, prev);
     }
 }
 
