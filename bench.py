@@ -328,6 +328,8 @@ def run_train(ctx, args, N, detailed=True):
     x = synthetic_images(N, 100 + ctx.rank, ctx.dev).to(ctx.dev)
     yd = torch.from_numpy(make_labels(N, C, 3 + ctx.rank)).to(ctx.dev)
     tr = Trainer(model, group=None, overlap=not args.no_overlap)
+    if args.update_after_layer is not None:
+        tr.update_after_layer = None if args.update_after_layer < 0 else args.update_after_layer
     state = {}
 
     def step():
@@ -434,6 +436,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the configs[2] / configs[3] measurements under "also"')
+    ap.add_argument('--update-after-layer', type=int, default=None,
+                    help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')
     ap.add_argument('--settle-ms', type=float, default=200.0, help='untimed steps after the warm-up until the clocks have settled')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],

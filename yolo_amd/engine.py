@@ -67,10 +67,14 @@ class DeviceModel:
         return ws
 
     # ------------------------------------------------------------------ forward pieces
-    def backbone(self, x, ws=None):
-        """x (N,H,W,3) f32 NHWC on the device -> features (N, 12544) (HWC flatten)."""
+    def backbone(self, x, ws=None, after_layer=None):
+        """x (N,H,W,3) f32 NHWC on the device -> features (N, 12544) (HWC flatten).
+        after_layer: optional (index, callable) - the callable runs on the host once layer `index` has been enqueued
+        (the trainer uses it to start the deferred Adam launch under the compute-bound layers)."""
         ws = ws or self.workspace(x.shape[0])
         for i, (layer, out) in enumerate(zip(self.conv, ws['acts'])):
+            if after_layer is not None and i == after_layer[0] + 1:
+                after_layer[1]()
             if self.dtype == 'bf16':
                 x = ops.conv3x3_bn_leaky_bf16(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA,
                                               out=out, workspace=ws['scratch'])
@@ -121,6 +125,8 @@ class Trainer:
     needs the new Dense weights: in front of the next Dense forward (step(..., wait=False)), or at the end of the
     step (wait=True, the default: the returned loss and the weights are then ordered on the caller's stream)."""
 
+    UPDATE_AFTER_LAYER = 4        # 14x14x256->512: in-call A/B tools/experiments/adam_defer_ab.sh, 1.050 -> 1.030 ms per step at 32 images
+
     def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None, overlap=True):
         if model.dtype != 'f32':
             raise ValueError("training runs in fp32 (the reference's arithmetic): build the model with dtype='f32'")
@@ -149,6 +155,12 @@ class Trainer:
         self.time_collective = False
         self.skip_collective = False     # measurement only (bench: step time without the exchange)
         self.fused_tail = True           # False: the three separate launches (same bits; kept for the comparison test)
+        # step(wait=False) only: the Adam launch of the update in flight is held back until the NEXT batch's backbone has
+        # enqueued this layer (None: it follows the all-reduce at once).  The first two layers are bound by their own
+        # instruction streams and by HBM, and the 516 MB Adam pass next to them costs them more than it hides; under the
+        # MFMA-bound layers behind them it is nearly free.  The all-reduce itself always starts at once.
+        self.update_after_layer = Trainer.UPDATE_AFTER_LAYER
+        self._adam_deferred = False
 
     def gradients(self, x, y_true):
         """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
@@ -174,13 +186,32 @@ class Trainer:
         ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
         return self.bucket.loss
 
+    def _launch_deferred_adam(self):
+        """The held-back Adam launch: on the side stream, behind the all-reduce already there and behind whatever the
+        compute stream has enqueued so far."""
+        if not self._adam_deferred:
+            return
+        self._adam_deferred = False
+        cur = torch.cuda.current_stream(self.device)
+        gate = torch.cuda.Event()
+        gate.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(gate)
+            self._adam()
+            self._updated.record(self.side)
+
     def join(self):
         """Make the current stream wait for the update in flight on the side stream (no host synchronisation)."""
+        self._launch_deferred_adam()
         if self._pending:
             torch.cuda.current_stream(self.device).wait_event(self._updated)
             self._pending = False
 
-    def _exchange_and_update(self):
+    def _adam(self):
+        self.t += 1
+        ops.adam_step(self.pflat, self.bucket.grads, self.m, self.v, self.t, self.lr, self.beta1, self.beta2, self.eps)
+
+    def _exchange_and_update(self, defer_adam=False):
         """ONE all-reduce of the bucket, the global loss copied out, ONE Adam launch - on the current stream."""
         if not self.skip_collective:
             if self.time_collective:
@@ -193,15 +224,18 @@ class Trainer:
                 e1.record()
                 self.collective_events = (e0, e1)
         loss = self.bucket.loss.clone()
-        self.t += 1
-        ops.adam_step(self.pflat, self.bucket.grads, self.m, self.v, self.t, self.lr, self.beta1, self.beta2, self.eps)
+        if defer_adam:
+            self._adam_deferred = True
+        else:
+            self._adam()
         return loss
 
     def step(self, x, y_true, wait=True):
         """x (n,448,448,3), y_true (n,S,S,C+5) on the device -> global batch loss (1,) on the device.
         wait=False leaves the exchange + update in flight on the side stream (the next step() or join() waits for it
         in front of its Dense forward); the returned loss is then valid only after join() / a device synchronise."""
-        feats = self.model.backbone(x, self.model.workspace(x.shape[0]))     # frozen: overlaps the update in flight
+        hook = (self.update_after_layer, self._launch_deferred_adam) if self._adam_deferred else None
+        feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the update in flight
         self.join()
         self.gradients_from_features(feats, y_true)
         if self.side is None:
@@ -210,8 +244,10 @@ class Trainer:
         self._grads_ready.record(cur)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self._grads_ready)
-            loss = self._exchange_and_update()
-            self._updated.record(self.side)
+            defer = not wait and self.update_after_layer is not None
+            loss = self._exchange_and_update(defer_adam=defer)
+            if not defer:
+                self._updated.record(self.side)
         loss.record_stream(cur)
         self._pending = True
         if wait:
