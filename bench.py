@@ -249,11 +249,17 @@ def run_infer(ctx, args, dtype, N, detailed=True):
     from yolo_amd import ops, params as P
     from yolo_amd.engine import DeviceModel
     C = 20
+    detailed = detailed and not args.graph      # a replayed graph has no per-launch brackets: no kernel table / roofline
+    C = 20
     prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
     model = DeviceModel(prm, C=C, device=ctx.dev, dtype=dtype)
     x_cpu = synthetic_images(N, 0, ctx.dev)
     x = x_cpu.to(ctx.dev)
     model.workspace(N)
+    if args.graph:                     # the batch lives in the graph's input buffer (no copy per step)
+        xin = model.input_buffer(N)
+        xin.copy_(x)
+        x = xin
     rec = gathered = None
     if ctx.multi:
         rec = torch.empty((N, 98, 6), dtype=torch.float64, device=ctx.dev)          # box(4) score cls*keep
@@ -261,7 +267,7 @@ def run_infer(ctx, args, dtype, N, detailed=True):
     state = {}
 
     def step():
-        boxes, score, cls, keep = model.detect(x)
+        boxes, score, cls, keep = model.detect_replay(x) if args.graph else model.detect(x)
         if ctx.multi:                                  # detection gather: fixed-size records, one collective
             ops.pack_detections(boxes, score, cls, keep, out=rec)
             if ctx.backend == 'nccl':
@@ -436,6 +442,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the configs[2] / configs[3] measurements under "also"')
+    ap.add_argument('--graph', action='store_true', help='inference: replay the step as one HIP graph (DeviceModel.detect_replay)')
     ap.add_argument('--update-after-layer', type=int, default=None,
                     help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')

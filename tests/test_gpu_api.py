@@ -369,3 +369,28 @@ def test_train_compile_save_reload_keeps_trained_weights(tmp_path):
     m2 = Model(inputs=inputs, outputs=outputs, seed=42)
     m2.load_weights(str(tmp_path / 't.npz'))
     np.testing.assert_array_equal(m2.predict(x), after)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_detect_replay_equals_detect(dtype):
+    """DeviceModel.detect_replay (one HIP-graph launch per batch) gives the bits of detect(): batch 1 (the reference's
+    per-frame detect), 3 and 20 (the fused inference tail), two different batches in a row through the same graph, and a
+    batch written straight into the graph's input buffer."""
+    prm = P.make_random_params(seed=5, dense_init='glorot', bn='identity')
+    model = DeviceModel(prm, device=DEV, dtype=dtype)
+    g = torch.Generator().manual_seed(9)
+    for N in (1, 3, 20):
+        for rep in range(2):
+            x = torch.rand((N, 448, 448, 3), generator=g).to(DEV)
+            want = [t.clone() for t in model.detect(x)]
+            if rep == 0:
+                got = model.detect_replay(x)
+            else:
+                buf = model.input_buffer(N)
+                buf.copy_(x)
+                got = model.detect_replay(buf)
+            torch.cuda.synchronize()
+            assert want[3].any(), 'the stress weights keep boxes'
+            for w, t in zip(want, got):
+                assert w.dtype == t.dtype and torch.equal(w.view(torch.uint8), t.view(torch.uint8))
+    assert len(model._graphs) == 3

@@ -40,6 +40,7 @@ class DeviceModel:
         self.K = self.dense_wt.shape[1]
         self.dense_wt_bf16 = ops.cast_bf16(self.dense_wt) if dtype == 'bf16' else None
         self._ws = {}
+        self._graphs, self._inputs = {}, {}
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, N):
@@ -110,6 +111,45 @@ class DeviceModel:
                                    y=ws['y'] if want_y else None, out=ws['det'])
 
 
+    # ------------------------------------------------------------------ one HIP-graph launch per batch
+    def detect_replay(self, x, iou_thr=0.2):
+        """detect() replayed as ONE HIP graph: the fixed launch sequence of a batch size (8 conv blocks, fix-ups, Dense,
+        head + decode + NMS) is captured once and then costs one host call instead of a dozen.  At batch 1 - the reference's
+        own use, tiny_yolov1.py:142-160 detect(image) per frame - the eager sequence is bound by the host's launch calls, not
+        by the GPU.  Same kernels, same buffers, same bits as detect().
+
+        x is copied into the graph's input buffer unless it IS that buffer (input_buffer(N): write the batch there and
+        pass it to skip the copy).  The returned tensors are the graph's outputs: valid until the next replay with this N."""
+        N = x.shape[0]
+        key = (N, float(iou_thr))
+        ent = self._graphs.get(key)
+        if ent is None:
+            xin = self.input_buffer(N)
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):          # first calls allocate the workspace: outside the capture
+                self.detect(xin, iou_thr)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.detect(xin, iou_thr)
+            ent = self._graphs[key] = (graph, out)
+        xin = self.input_buffer(N)
+        if x.data_ptr() != xin.data_ptr():
+            xin.copy_(x)
+        ent[0].replay()
+        return ent[1]
+
+    def input_buffer(self, N):
+        """The (N, img, img, 3) fp32 batch the graphs of batch size N read."""
+        buf = self._inputs.get(N)
+        if buf is None:
+            buf = self._inputs[N] = torch.zeros((N, self.img_size, self.img_size, 3), dtype=torch.float32, device=self.device)
+        return buf
+
+
 class Trainer:
     """One training step of the reference's configuration (train.py:59-60): the frozen
     backbone and the Dense layer run forward, yolo_loss gives dL/dy_pred in closed form, the head
@@ -143,6 +183,7 @@ class Trainer:
         self.pflat[:n_w].view(rows, ldk).copy_(model.dense_wt)
         self.pflat[n_w:].copy_(model.dense_b)
         model.dense_wt, model.dense_b = self.pflat[:n_w].view(rows, ldk), self.pflat[n_w:]
+        model._graphs.clear()            # captured graphs hold the old parameter addresses
         self.m, self.v = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
         self.t = 0
         self.ldz = ops.round_up(model.units, 4)
