@@ -95,7 +95,7 @@ class DeviceModel:
         ws = self.workspace(x.shape[0])
         return self.head(self.backbone(x, ws), ws)
 
-    FUSED_TAIL_MIN_BATCH = 16      # below it one workgroup per image leaves the split-K reduction too serial
+    FUSED_TAIL_MIN_BATCH = 1       # (with 85 Dense splits the two-launch tail won below 16 images; with 21 the fused one wins from 1)
 
     def detect(self, x, iou_thr=0.2, want_y=False):
         """-> (boxes f64 (N,S*S*B,4), score, cls, keep) on the device.  From FUSED_TAIL_MIN_BATCH images on, everything

@@ -153,15 +153,20 @@ def preprocess_u8(img_u8, out_hw=(448, 448), swap_rb=False, out=None):
     return out
 
 
-def pick_splits(K, n_rows, units, slots=512, chunk=DENSE_K_ALIGN):
-    """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills whole rounds of
-    `slots` resident blocks (2 per CU), with at least 4 chunks (32 floats / 64 bf16 of K) per slice."""
+def pick_splits(K, n_rows, units, slots=None, chunk=DENSE_K_ALIGN):
+    """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills ONE round of `slots`
+    resident blocks, with at least 4 chunks (32 floats / 64 bf16 of K) per slice.  slots: 2 per CU for the 64 x 64 tiles
+    of batches above 32, 1 per CU for the 32 x 128 tiles below (every extra split is one more partial for the kernel
+    behind the GEMM to reduce: measured with tools/experiments/dense_splits.py, GEMM + tail at 32 images 52 -> 34 us
+    with 21 splits instead of 85, at one image 49 -> 40 us)."""
     chunks = K // chunk
     tiles = ((n_rows + 63) // 64) * ((units + 63) // 64) if n_rows > 32 else (units + 127) // 128
+    if slots is None:
+        slots = 512 if n_rows > 32 else 256
     best, best_eff = 1, 0.0
     for s in range(1, max(1, chunks // 4) + 1):
         blocks = tiles * s
-        if blocks > 2 * slots:
+        if blocks > slots:
             break
         eff = blocks / (-(-blocks // slots) * slots)
         if eff > best_eff + 1e-9:
