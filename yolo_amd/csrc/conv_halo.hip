@@ -1,5 +1,6 @@
 // 3x3 conv + folded BN + LeakyReLU (+ 2x2 max-pool) blocks of the bf16 network on an LDS-resident input halo
-// (v_mfma_f32_32x32x16_bf16; /root/reference/models/model_tiny_yolov1.py:52-84, the blocks with Cin = 32 ... 512).
+// (v_mfma_f32_16x16x32_bf16, 4 x 4 blocks per wave; /root/reference/models/model_tiny_yolov1.py:52-84, the blocks with
+// Cin = 32 ... 512).
 //
 // Why a second kernel next to conv_persist_kernel (conv_gemm.hip): that loop fetches a 128-byte row of A per output
 // pixel, tap and K chunk - the im2col matrix, every activation nine times - and in bf16 the fetch, not the matrix pipe,
@@ -9,22 +10,24 @@
 //   * the (PH+2) x (PW+2) halo of a 64-byte or 128-byte K chunk is moved to LDS ONCE (LDS-DMA, zeros outside the image)
 //     and serves all nine taps: a tap is a constant shift of the fragment address;
 //   * the weights stream through a ring of four stages (one tap x BN channels x chunk), fetched three stages ahead
-//     (counted vmcnt, raw s_barrier; fragments are read two k-steps ahead of their MFMAs across the stage barriers), or
+//     (counted vmcnt, raw s_barrier; fragments are read one 32-k step ahead of their MFMAs across the stage barriers), or
 //     - when all of them fit (Cin = 32: 36 KB) - are loaded once and stay;
 //   * the halo of the next chunk / next patch lands in the other halo buffer while this one multiplies.
-// LDS-DMA bytes per MFMA drop from 512 to 160-270.  Bank conflicts: a pixel's (a weight row's) 16-byte K slots are
-// XOR-swizzled with the low bits of its index on the source side of the DMA; a fragment read is
-// base(lane, tap) ^ (k-step << 5) (+ immediate); switching halo buffers adds +-(buffer size) to the 18 bases.
+// LDS-DMA bytes per FLOP drop to a third ... a half.  Bank conflicts: a pixel's (a weight row's) 16-byte K slots are
+// XOR-swizzled with a key from its index (and, for pixels, its halo row) on the source side of the DMA; a fragment read is
+// base(lane, tap) ^ (k-step << 6) (+ immediate); switching halo buffers adds +-(buffer size) to the 36 bases.
 // Epilogue as in conv_persist_kernel: BN, 2x2 max over four accumulator registers, LeakyReLU once, bf16 store.
 // Instantiations and what the dispatcher requires of a layer: conv3x3_halo_bf16_supported() at the end of this file.
 #include "common.h"
 
 #include <atomic>
 #include <cstdint>
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *lds_ptr;
 constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -37,7 +40,7 @@ struct HaloArgs {
     int NB, H, W, Cin, Cout;
     float alpha;
     int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
-    int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue
+    int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered
 };
 #ifdef TY1_DEV_STAMPS
 #define HALO_DBG(bit) ((a.dbg & (bit)) != 0)
@@ -54,17 +57,33 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to n
 // RES_B: Cin == CK and Cout == BN - the whole weight tensor (9 x BN x CK) is loaded once and stays in LDS.
 // NI > 1 (layers without a pool, whole maps): an item is NI consecutive images of PH x PW = H x W pixels, each with its own
 // ring of zeros in LDS; GEMM rows in natural order (image, y, x), every accumulator is stored.
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1>
+// FM x FN: accumulator blocks per wave.  M16: the blocks are 16 x 16 (v_mfma_f32_16x16x32_bf16, one fragment read = 16 rows x
+// 32 k) instead of 32 x 32 (v_mfma_f32_32x32x16_bf16, 32 rows x 16 k): the same reads, bytes and matrix cycles per FLOP, but
+// on random operands the chip holds a higher clock under the 16 x 16 shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_halo_bf16_kernel(const HaloArgs a) {
+    constexpr int BS = M16 ? 16 : 32;                                  // rows / columns of an accumulator block
+    constexpr int KS = M16 ? 32 : 16, KSH = M16 ? 6 : 5;               // k per MFMA; log2 of its bytes in a row
+    constexpr int GW = M16 ? 1 : 4;                                    // pool windows of a block held by one lane (4 registers each)
+    using Acc = typename std::conditional<M16, f32x4, f32x16>::type;
     constexpr bool POOL = NI == 1;
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int CKB = CK * 2, NSLOT = CKB / 16, NS16 = CK / 16;      // bytes, 16-byte slots, k16 steps per chunk row
+    constexpr int CKB = CK * 2, NSLOT = CKB / 16, NS16 = CK / KS;      // bytes, 16-byte slots, MFMA k-steps per chunk row
     constexpr int HWD = PW + 2, HPI = (PH + 2) * HWD, HPIX = NI * HPI; // halo width, halo pixels per image, halo pixels
     constexpr int PIXPP = 1024 / CKB;                                  // pixels (rows) per 1 KiB DMA piece
     // swizzle key of row (pixel / weight row) idx: rows idx and idx + RPW start on the same bank, so the key changes every
     // RPW rows and 16 consecutive rows give 16 distinct (start bank, slot) pairs = all 64 banks for a ds_read_b128 group
     constexpr int RPW = 256 / CKB;
     auto key_of = [](int idx) { return (idx / RPW) & (NSLOT - 1); };
+    // halo pixels: a 16-lane group of a fragment read covers pixels of two or three halo rows, and with a key from the pixel
+    // index alone the rows collide (1.75-2.0 passes per group in a model of the bank mapping, SQ_LDS_BANK_CONFLICT agrees);
+    // the halo row enters the key with a coefficient searched per patch shape (1.1-1.3 passes; 1.67 for 16 x 16 x 32 channels)
+    constexpr int KA = (CK == 32 && PW == 16) ? 2 : 0;
+    constexpr int KC = (CK == 32 && PW == 16) ? 1 : (CK == 32 && PW == 14) ? 2 : PW == 28 ? 5 : PW == 14 ? 4 : PW == 7 ? 7 : 0;
+    auto key_px = [&](int hp) {
+        const int row = hp / HWD;
+        return ((hp + KA * row) / RPW + KC * row) & (NSLOT - 1);
+    };
     constexpr int HP = (HPIX + PIXPP - 1) / PIXPP;                     // halo pieces
     constexpr int HPW = (HP + NW - 1) / NW;                            // ... per wave
     constexpr int HALO1 = HP * 1024;                                   // byte distance of the two halo buffers
@@ -72,8 +91,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NW;    // bytes, pieces, pieces per wave
     constexpr int BOFF = HALO1 + HP * 1024;
     constexpr int MPIX = NI * PH * PW, WINS = MPIX / 4;
-    static_assert(BN == 64 * WAVES_N, "a wave owns 64 x 64 of the tile");
-    static_assert(MPIX <= 64 * WAVES_M && (!POOL || (MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0)), "patch shape");
+    static_assert(BN == BS * FN * WAVES_N, "a wave owns (BS FM) x (BS FN) of the tile");
+    static_assert(MPIX <= BS * FM * WAVES_M && (!POOL || (MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0)), "patch shape");
     static_assert(BP % NW == 0, "weight pieces divide among the waves");
     static_assert(RES_B || HPW <= NSC, "one halo piece per wave and stage");
     static_assert(BOFF + NRING * STAGE <= 160 * 1024, "LDS");
@@ -84,14 +103,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int G = gridDim.x;
     const int nch = a.Cin / CK;
-    const int frag_row = lane & 31, h = lane >> 5;
+    const int frag_row = lane & (BS - 1), h = lane / BS;               // row of a block, 16-byte k slot within an MFMA step
     const int Ho = a.H >> 1, Wo = a.W >> 1;
 
     // ---- fragment read bases.  A: pixel of GEMM row m (pool-window order) shifted by the tap, slot h of k-step 0.
-    unsigned abase[2][9];
+    unsigned abase[FM][9];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = wave_m * 64 + 32 * i + frag_row;
+    for (int i = 0; i < FM; ++i) {
+        int m = wave_m * (BS * FM) + BS * i + frag_row;
         if (m >= MPIX) m = 0;                                          // padding rows: any valid pixel, never stored
         int py, px, sub = 0;
         if (POOL) {
@@ -107,14 +126,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hp = sub * HPI + (py + t / 3) * HWD + px + t % 3;
-            abase[i][t] = (unsigned)(hp * CKB + ((h ^ key_of(hp)) << 4));
+            abase[i][t] = (unsigned)(hp * CKB + ((h ^ key_px(hp)) << 4));
         }
     }
     unsigned bbase[NS16];                                              // B: weight row of this lane, slot of k-step s
     {
-        const int n_l = wave_n * 64 + frag_row;
+        const int n_l = wave_n * (BS * FN) + frag_row;
 #pragma unroll
-        for (int s = 0; s < NS16; ++s) bbase[s] = (unsigned)(BOFF + n_l * CKB + (((2 * s + h) ^ key_of(n_l)) << 4));
+        for (int s = 0; s < NS16; ++s) bbase[s] = (unsigned)(BOFF + n_l * CKB + ((((KS / 8) * s + h) ^ key_of(n_l)) << 4));
     }
 
     // ---- DMA geometry of this lane: row dl_row of a piece, 16-byte slot dl_slot
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
         const int hp = (wave + NW * k) * PIXPP + dl_row, sub = hp / HPI, hr = hp - sub * HPI, hy = hr / HWD, hx = hr - hy * HWD;
-        voff_h[k] = (unsigned)((((sub * a.H + hy) * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_of(hp)) << 4));
+        voff_h[k] = (unsigned)((((sub * a.H + hy) * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_px(hp)) << 4));
         hyx[k] = hp < HPIX && wave + NW * k < HP ? (hy | (hx << 8) | (sub << 16)) : -1;
     }
     const __amdgpu_buffer_rsrc_t b_rsrc =
@@ -185,57 +204,62 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
                                                      (int)voff_b[k], soff, 0, 0);
     };
 
-    // ---- output geometry: lane holds channel (lane & 31) of tile column j; accumulator registers 4g .. 4g+3 of block i
-    //      are the four pixels of pool window wave_m * 16 + 8i + 2g + h of the patch
-    unsigned woff[2][4];
+    // ---- output geometry: lane holds channel (lane & (BS - 1)) of block column j; accumulator registers 4g .. 4g+3 of block
+    //      i are the four pixels of pool window wave_m * (BS / 4) FM + (BS / 4) i + 2g + h (32 x 32 blocks) or ... + h (16 x 16)
+    unsigned woff[FM][GW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int w = wave_m * 16 + 8 * i + 2 * g + h;
+        for (int g = 0; g < GW; ++g) {
+            const int w = wave_m * (BS / 4 * FM) + BS / 4 * i + (M16 ? h : 2 * g + h);
             woff[i][g] = w < WINS ? (unsigned)(((w / (PW / 2)) * Wo + w % (PW / 2)) * a.Cout * 2) : kNoStore;
         }
     const long long y_bytes = (long long)a.NB * Ho * Wo * a.Cout * 2;
 
-    f32x16 acc[2][2];
+    Acc acc[FM][FN];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4 * GW; ++r) acc[i][j][r] = 0.f;
     };
+    // fragment ring: reads run AH k-steps ahead of their MFMAs (a 16 x 16 x 32 step is as long as two 32 x 32 x 16 steps)
+    constexpr int RD = M16 ? 2 : 3, AH = RD - 1;
     struct Frag {
-        bf16x8 a[2], b[2];
+        bf16x8 a[FM], b[FN];
     };
     // k-step s of tap `tap`; the weights of that tap are rows [tb * BN, (tb + 1) * BN) of ring slot `slot`
     auto read_frag = [&](Frag &f, int tap, int s, int slot, int tb) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[abase[i][tap] ^ (unsigned)(s << 5)], 16));
+        for (int i = 0; i < FM; ++i)
+            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[abase[i][tap] ^ (unsigned)(s << KSH)], 16));
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
             f.b[j] = *reinterpret_cast<const bf16x8 *>(
-                __builtin_assume_aligned(&lds[bbase[s] + (unsigned)(slot * STAGE + (tb * BN + 32 * j) * CKB)], 16));
+                __builtin_assume_aligned(&lds[bbase[s] + (unsigned)(slot * STAGE + (tb * BN + BS * j) * CKB)], 16));
     };
     auto mfma = [&](const Frag &f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+            }
     };
     // (resident weights) all k-steps of a patch, fragments read two k-steps ahead of their MFMAs
     auto compute_stage = [&](int st) {
         constexpr int STEPS = TS * NS16;
         const int slot = RES_B ? 0 : st % 3;
-        Frag f[3];                                             // fragments run two k-steps ahead of their MFMAs
+        Frag f[RD];                                            // fragments run AH k-steps ahead of their MFMAs
         read_frag(f[0], st * TS, 0, slot, 0);
-        if (STEPS > 1) read_frag(f[1], st * TS + 1 / NS16, 1 % NS16, slot, 1 / NS16);
+        if (AH > 1 && STEPS > 1) read_frag(f[1], st * TS + 1 / NS16, 1 % NS16, slot, 1 / NS16);
 #pragma unroll
         for (int q = 0; q < STEPS; ++q) {
-            if (q + 2 < STEPS) read_frag(f[(q + 2) % 3], st * TS + (q + 2) / NS16, (q + 2) % NS16, slot, (q + 2) / NS16);
-            mfma(f[q % 3]);
+            if (q + AH < STEPS) read_frag(f[(q + AH) % RD], st * TS + (q + AH) / NS16, (q + AH) % NS16, slot, (q + AH) / NS16);
+            mfma(f[q % RD]);
         }
     };
     auto wg_barrier = [&] {
@@ -248,35 +272,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     //      ahead into a ring of four, and the barrier that ends a stage waits only for the reads older than the eight
     //      (two k-steps) that already belong to the next stage.
     constexpr int Q = NSC * NS16;
-    static_assert(RES_B || Q % 3 == 0, "the fragment ring keeps its phase from step to step");
-    Frag fr[3];
+    static_assert(RES_B || Q % RD == 0, "the fragment ring keeps its phase from step to step");
+    Frag fr[RD];
     int gs = 0;                                 // stages so far: stage g of this workgroup lives in ring slot g & 3
     auto read_stream = [&](Frag &f, int tap, int s, unsigned boff, unsigned hd) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[(abase[i][tap] + hd) ^ (unsigned)(s << 5)], 16));
+        for (int i = 0; i < FM; ++i)
+            f.a[i] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[(abase[i][tap] + hd) ^ (unsigned)(s << KSH)], 16));
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            f.b[j] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[bbase[s] + boff + (unsigned)(32 * j * CKB)], 16));
+        for (int j = 0; j < FN; ++j)
+            f.b[j] = *reinterpret_cast<const bf16x8 *>(__builtin_assume_aligned(&lds[bbase[s] + boff + (unsigned)(BS * j * CKB)], 16));
     };
     auto stage_barrier = [&] {
         if (HALO_DBG(4)) return;
-        asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
+        // (the two k-steps read ahead are 2 (FM + FN) reads; the counter holds 15 at most, a stricter wait is harmless)
+        constexpr int AHEAD = AH * (FM + FN) < 15 ? AH * (FM + FN) : 15;
+        asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(AHEAD) : "memory");
     };
 
     // BN scale / shift of the item's channels: loaded when its first step starts, pinned behind that step's first wait
-    float sc[2], sh[2];
+    float sc[FN], sh[FN];
     auto load_bn = [&](const Step &d) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = d.nt * BN + wave_n * 64 + 32 * j + (lane & 31);
+        for (int j = 0; j < FN; ++j) {
+            const int n = d.nt * BN + wave_n * (BS * FN) + BS * j + frag_row;
             sc[j] = a.scale[n];
             sh[j] = a.shift[n];
         }
     };
     auto landed = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
     };
     auto epilogue = [&](const Step &d) {
         if constexpr (!POOL) {
@@ -287,16 +313,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
                 static_cast<char *>(a.y) + (long long)d.img * (PH * PW) * a.Cout * 2, 0, imgs * (PH * PW) * a.Cout * 2, 0x00020000);
             const unsigned row_b = (unsigned)a.Cout * 2u;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const unsigned vb = (unsigned)(wave_m * 64 + 4 * h) * row_b + (unsigned)(d.nt * BN + wave_n * 64 + 32 * j + (lane & 31)) * 2u;
+            for (int j = 0; j < FN; ++j) {
+                const unsigned vb = (unsigned)(wave_m * (BS * FM) + 4 * h) * row_b + (unsigned)(d.nt * BN + wave_n * (BS * FN) + BS * j + frag_row) * 2u;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 4 * GW; ++r) {
                         float t = acc[i][j][r] * sc[j] + sh[j];
                         t = t > 0.f ? t : t * a.alpha;
                         __builtin_amdgcn_raw_buffer_store_b16(bf16_bits(t), o_rsrc, (int)vb,
-                                                              (32 * i + (r & 3) + 8 * (r >> 2)) * (int)row_b, 0);
+                                                              (BS * i + (r & 3) + (M16 ? 0 : 8 * (r >> 2))) * (int)row_b, 0);
                     }
             }
             return;
@@ -306,12 +332,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             static_cast<char *>(a.y) + o_org, 0, (int)(left > 0x7FFFFFFFll ? 0x7FFFFFFFll : left), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = d.nt * BN + wave_n * 64 + 32 * j + (lane & 31);
+        for (int j = 0; j < FN; ++j) {
+            const int n = d.nt * BN + wave_n * (BS * FN) + BS * j + frag_row;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < GW; ++g) {
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = acc[i][j][4 * g + q] * sc[j] + sh[j];
@@ -339,9 +365,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     int hbuf = 0;
     if (!RES_B) {
         read_stream(fr[0], 0, 0, 0u, 0u);
-        read_stream(fr[1], 1 / NS16, 1 % NS16, 0u, 0u);
+        if (AH > 1) read_stream(fr[1], 1 / NS16, 1 % NS16, 0u, 0u);
     }
 
+    // developer switch: the two waves of a SIMD (wave w and w + NW / 2) issue their LDS-DMA at different points of a stage
+    // (-1 ... -1.5 % on a layer timed alone, +2 ... +3 % on the whole network: off)
+    const bool late = HALO_DBG(16) && NW >= 8 && wave >= NW / 2;
     while (cur.live) {
         const Step nxt = step_of(u + 1);
         if (u > 0 && cur.c == 0) load_bn(cur);
@@ -358,16 +387,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
             for (int st = 0; st < NSC; ++st) {
                 // fetch: one halo piece of the next step, then the weights three stages ahead (ring slot last read in stage st - 1)
-                if (st < HPW) dma_halo(nxt, st, hbuf ^ 1);
-                if (st + 3 < NSC) dma_b(cur, st + 3, (gs + 3) & 3);
-                else dma_b(nxt, st + 3 - NSC, (gs + 3) & 3);
+                auto fetch = [&] {
+                    if (st < HPW) dma_halo(nxt, st, hbuf ^ 1);
+                    if (st + 3 < NSC) dma_b(cur, st + 3, (gs + 3) & 3);
+                    else dma_b(nxt, st + 3 - NSC, (gs + 3) & 3);
+                };
+                if (!late) fetch();
                 const unsigned boff_cur = (unsigned)((gs & 3) * STAGE), boff_nxt = (unsigned)(((gs + 1) & 3) * STAGE);
 #pragma unroll
                 for (int ks = 0; ks < NS16; ++ks) {
-                    const int q = st * NS16 + ks, q2 = q + 2, st2 = q2 / NS16, s2 = q2 % NS16;
-                    if (q2 < Q) read_stream(fr[q2 % 3], st2, s2, st2 == st ? boff_cur : boff_nxt, 0u);
-                    else read_stream(fr[q2 % 3], st2 - NSC, s2, boff_nxt, hd_next);      // first k-steps of the next step
-                    mfma(fr[q % 3]);
+                    if (late && ks == NS16 / 2) fetch();
+                    const int q = st * NS16 + ks, q2 = q + AH, st2 = q2 / NS16, s2 = q2 % NS16;
+                    if (q2 < Q) read_stream(fr[q2 % RD], st2, s2, st2 == st ? boff_cur : boff_nxt, 0u);
+                    else read_stream(fr[q2 % RD], st2 - NSC, s2, boff_nxt, hd_next);      // first k-steps of the next step
+                    mfma(fr[q % RD]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the PB newest DMAs of this wave (stage st + 3) may stay in flight; everything older - stage st + 2, the
@@ -385,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         {
             const unsigned delta = hbuf ? (unsigned)-HALO1 : (unsigned)HALO1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int t = 0; t < 9; ++t) abase[i][t] += delta;
         }
@@ -406,7 +439,7 @@ int num_cus_here() {       // cached per device id (one process may drive severa
     return cus;
 }
 
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1>
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false>
 int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     a.tiles_x = a.W / PW;
     a.tiles_y = a.H / PH;
@@ -417,7 +450,7 @@ int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     const long long want = (long long)per_cu * num_cus_here();
     const double px = (double)a.NB * a.H * a.W;
     ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
-    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI>
+    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI, FM, FN, M16>
         <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
     return ty1::check_launch(name);
 }
@@ -460,10 +493,18 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha;
     if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
-    if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
-    if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
-    if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
-    return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+    // every wave owns 64 x 64 of the tile as 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 (in-call A/Bs against 2 x 2 blocks of
+    // 32x32x16: -1.5 ... -3 % per layer timed alone; whole bf16 network +5.4, +4.4, +0.4 and -1.5 % images/s on four devices)
+    if (ty1::dev_env("TY1_HALO_M32")) {          // developer override: 2 x 2 blocks of 32x32x16
+        if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
+        if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
+        if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
+        return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+    }
+    if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>("conv_halo_bf16_4x7x7", a, 1, s);
+    if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true>("conv_halo_bf16_c32", a, 2, s);
+    if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false, 1, 4, 4, true>("conv_halo_bf16_14x14", a, 1, s);
+    return launch_halo<64, 128, 4, 2, 8, 28, false, 1, 4, 4, true>("conv_halo_bf16_8x28", a, 1, s);
 }
 
 }  // namespace ty1
