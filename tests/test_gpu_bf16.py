@@ -48,9 +48,18 @@ def _case(N, H, cin, cout, pool, out_f32, seed, use_ws):
     if use_ws:
         nbytes = ops.conv3x3_workspace_bytes_bf16(N, H, H, cin, cout, pool)
         ws = torch.full((max(nbytes, 16) // 4,), float('nan'), dtype=torch.float32, device=DEV)
+    # the output sits between two guard regions: a kernel that leans on the range check of its output descriptor (ragged last
+    # work items, padding rows) must not write a byte outside the tensor
+    out_dt = torch.float32 if out_f32 else torch.bfloat16
+    oshape = (N, H // 2, H // 2, cout) if pool else (N, H, H, cout)
+    numel, guard = int(np.prod(oshape)), 1 << 20
+    buf = torch.full((numel + 2 * guard,), 77.0, dtype=out_dt, device=DEV)
+    out = buf[guard:guard + numel].view(oshape)
     got = ops.conv3x3_bn_leaky_bf16(dev(x, in_dt), dev(P.hwio_to_ohwi(w), in_dt), dev(scale), dev(shift), pool,
-                                    out_f32=out_f32, workspace=ws)
-    assert got.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+                                    out_f32=out_f32, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    assert got.dtype == out_dt
+    assert bool((buf[:guard] == 77.0).all()) and bool((buf[guard + numel:] == 77.0).all()), 'write outside the output tensor'
     return got.float().cpu().numpy(), ref
 
 

@@ -118,7 +118,15 @@ def _conv_case(N, H, cin, cout, pool, seed, use_ws=False, alpha=0.1):
     if use_ws:      # the K-split tail path (csrc/conv_gemm.hip plan_tail); poison the scratch to catch unwritten partials
         nbytes = ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool)
         ws = torch.full((max(nbytes, 16) // 4,), float('nan'), dtype=torch.float32, device=DEV)
-    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool, alpha=alpha, workspace=ws).cpu().numpy()
+    # the output sits between two guard regions: no kernel may write a byte outside the tensor (ragged tiles, padding rows)
+    oshape = (N, H // 2, H // 2, cout) if pool else (N, H, H, cout)
+    numel, guard = int(np.prod(oshape)), 1 << 18
+    buf = torch.full((numel + 2 * guard,), 77.0, dtype=torch.float32, device=DEV)
+    out = buf[guard:guard + numel].view(oshape)
+    got = ops.conv3x3_bn_leaky(dev(x), dev(P.hwio_to_ohwi(w)), dev(scale), dev(shift), pool, alpha=alpha, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 77.0).all()) and bool((buf[guard + numel:] == 77.0).all()), 'write outside the output tensor'
+    got = got.cpu().numpy()
     return got, ref
 
 
