@@ -10,10 +10,40 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='64,16,512,1024,0')
 ap.add_argument('--persist', action='store_true', help='stamps written by conv_persist_kernel')
 ap.add_argument('--direct', action='store_true', help='stamps written by the first-layer persistent kernel (TY1_DEV_STAMPS build)')
+ap.add_argument('--halo', action='store_true', help='stamps written by conv_halo_bf16_kernel (bf16 layer, dev build): where wave 0 of every workgroup spends its cycles')
 ap.add_argument('--launches', type=int, default=30)
 args = ap.parse_args()
 n, hh, cin, cout, pool = (int(v) for v in args.shape.split(','))
 dev = 'cuda:0'
+if args.halo:
+    xb = torch.rand((n, hh, hh, cin), device=dev).to(torch.bfloat16)
+    wb = (torch.randn((cout, 3, 3, cin), device=dev) * 0.05).to(torch.bfloat16)
+    sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    out = ops.conv3x3_bn_leaky_bf16(xb, wb, sc, sh, bool(pool))
+    cap = 1 << 12
+    buf = torch.zeros((cap, 8), dtype=torch.int64, device=dev)
+    for _ in range(200):
+        ops.conv3x3_bn_leaky_bf16(xb, wb, sc, sh, bool(pool), out=out)
+    torch.cuda.synchronize()
+    _lib.call('ty1_debug_stamp_buffer', buf.data_ptr(), cap)
+    for _ in range(args.launches):
+        ops.conv3x3_bn_leaky_bf16(xb, wb, sc, sh, bool(pool), out=out)
+    torch.cuda.synchronize()
+    _lib.call('ty1_debug_stamp_buffer', None, 0)
+    b = buf.cpu().numpy()
+    b = b[b[:, 0] != 0]
+    t0 = b[:, 0].min()
+    st, end = (b[:, 0] - t0) / 100.0, (b[:, 3] - t0) / 100.0
+    ns = np.maximum(b[:, 7], 1).astype(np.float64)
+    tot = b[:, 1] + b[:, 2] + b[:, 4]
+    nw = 8 if len(b) % 8 == 0 and len(b) >= 2048 else 4
+    print(f'waves {len(b)} ({nw} per workgroup)  span {end.max():.1f} us  wave time {np.mean(end - st):.1f} us  stages/wave {ns.mean():.0f}')
+    for w in range(nw):
+        r = b[w::nw]; n_ = ns[w::nw]; t_ = tot[w::nw]
+        print(f'wave {w}: per stage (shader cycles): issue of fetch + MFMA steps {np.mean(r[:, 1] / n_):6.0f}  vmcnt wait {np.mean(r[:, 2] / n_):5.0f}  '
+              f'lgkmcnt + barrier {np.mean(r[:, 4] / n_):5.0f}  sum {np.mean(t_ / n_):6.0f}   epilogues {np.mean(r[:, 5]):6.0f}')
+    print(f'shader clock (stamped cycles / wave time) {np.mean((tot + b[:, 5]) / np.maximum(end - st, 1e-9)) / 1e3:.3f} GHz')
+    sys.exit(0)
 x = torch.rand((n, hh, hh, cin), device=dev)
 w = torch.randn((cout, 3, 3, cin), device=dev) * 0.05
 sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)

@@ -40,12 +40,15 @@ struct HaloArgs {
     int NB, H, W, Cin, Cout;
     float alpha;
     int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
+    long long *stamp;                            // developer timeline (dev build only; 8 x i64 per wave, tools/stamp_trace.py --halo)
     int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered
 };
 #ifdef TY1_DEV_STAMPS
 #define HALO_DBG(bit) ((a.dbg & (bit)) != 0)
+#define HALO_STAMP(var) do { if (do_stamp) { __builtin_amdgcn_sched_barrier(0); var = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define HALO_DBG(bit) false
+#define HALO_STAMP(var) do { } while (0)
 #endif
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to nearest even
@@ -60,7 +63,9 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to n
 // FM x FN: accumulator blocks per wave.  M16: the blocks are 16 x 16 (v_mfma_f32_16x16x32_bf16, one fragment read = 16 rows x
 // 32 k) instead of 32 x 32 (v_mfma_f32_32x32x16_bf16, 32 rows x 16 k): the same reads, bytes and matrix cycles per FLOP, but
 // on random operands the chip holds a higher clock under the 16 x 16 shape (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false>
+// NL: the first NL waves of the workgroup issue all LDS-DMA (default: every wave its share).
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false,
+          int NL = WAVES_M * WAVES_N>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int BS = M16 ? 16 : 32;                                  // rows / columns of an accumulator block
     constexpr int KS = M16 ? 32 : 16, KSH = M16 ? 6 : 5;               // k per MFMA; log2 of its bytes in a row
@@ -85,22 +90,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         return ((hp + KA * row) / RPW + KC * row) & (NSLOT - 1);
     };
     constexpr int HP = (HPIX + PIXPP - 1) / PIXPP;                     // halo pieces
-    constexpr int HPW = (HP + NW - 1) / NW;                            // ... per wave
+    constexpr int HPW = (HP + NL - 1) / NL;                            // ... per loading wave
     constexpr int HALO1 = HP * 1024;                                   // byte distance of the two halo buffers
     constexpr int TS = RES_B ? 9 : 1, NSC = 9 / TS, NRING = RES_B ? 1 : 4;   // taps per stage, stages per chunk, ring
-    constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NW;    // bytes, pieces, pieces per wave
+    constexpr int STAGE = TS * BN * CKB, BP = STAGE / 1024, PB = BP / NL;    // bytes, pieces, pieces per loading wave
     constexpr int BOFF = HALO1 + HP * 1024;
     constexpr int MPIX = NI * PH * PW, WINS = MPIX / 4;
     static_assert(BN == BS * FN * WAVES_N, "a wave owns (BS FM) x (BS FN) of the tile");
     static_assert(MPIX <= BS * FM * WAVES_M && (!POOL || (MPIX % 4 == 0 && PH % 2 == 0 && PW % 2 == 0)), "patch shape");
-    static_assert(BP % NW == 0, "weight pieces divide among the waves");
-    static_assert(RES_B || HPW <= NSC, "one halo piece per wave and stage");
+    static_assert(BP % NL == 0 && NL <= NW, "weight pieces divide among the loading waves");
+    static_assert(RES_B || HPW <= 2 * NSC, "at most two halo pieces per wave and stage");
     static_assert(BOFF + NRING * STAGE <= 160 * 1024, "LDS");
     static_assert(PH + 2 < 256 && PW + 2 < 256, "halo coordinates are packed in bytes");
     __shared__ __attribute__((aligned(1024))) char lds[BOFF + NRING * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const bool is_loader = NL == NW || wave < NL;
     const int G = gridDim.x;
     const int nch = a.Cin / CK;
     const int frag_row = lane & (BS - 1), h = lane / BS;               // row of a block, 16-byte k slot within an MFMA step
@@ -141,16 +147,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     unsigned voff_b[PB];                                               // weight pieces wave + NW * k of a stage
 #pragma unroll
     for (int k = 0; k < PB; ++k) {
-        const int r = (wave + NW * k) * PIXPP + dl_row, n = r % BN, t = r / BN;
+        const int r = (wave + NL * k) * PIXPP + dl_row, n = r % BN, t = r / BN;
         voff_b[k] = (unsigned)(((n * 9 + t) * a.Cin) * 2 + ((dl_slot ^ key_of(r)) << 4));
     }
     unsigned voff_h[HPW];                                              // halo pieces wave + NW * k
     int hyx[HPW];
 #pragma unroll
     for (int k = 0; k < HPW; ++k) {
-        const int hp = (wave + NW * k) * PIXPP + dl_row, sub = hp / HPI, hr = hp - sub * HPI, hy = hr / HWD, hx = hr - hy * HWD;
+        const int hp = (wave + NL * k) * PIXPP + dl_row, sub = hp / HPI, hr = hp - sub * HPI, hy = hr / HWD, hx = hr - hy * HWD;
         voff_h[k] = (unsigned)((((sub * a.H + hy) * a.W + hx) * a.Cin) * 2 + ((dl_slot ^ key_px(hp)) << 4));
-        hyx[k] = hp < HPIX && wave + NW * k < HP ? (hy | (hx << 8) | (sub << 16)) : -1;
+        hyx[k] = hp < HPIX && wave + NL * k < HP ? (hy | (hx << 8) | (sub << 16)) : -1;
     }
     const __amdgpu_buffer_rsrc_t b_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.w), 0, (int)((long long)a.Cout * 9 * a.Cin * 2), 0x00020000);
@@ -190,17 +196,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const int hy = hyx[k] & 0xFF, hx = (hyx[k] >> 8) & 0xFF, sub = hyx[k] >> 16;
         const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W &&
                         d.img + sub < a.NB;
-        if (wave + NW * k < HP && !HALO_DBG(1))
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(lds + buf * HALO1 + (wave + NW * k) * 1024), 16,
+        if (is_loader && wave + NL * k < HP && !HALO_DBG(1))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(lds + buf * HALO1 + (wave + NL * k) * 1024), 16,
                                                      (int)(ok ? voff_h[k] : kOOB), soff, 0, 0);
     };
     // the PB weight pieces of this wave for stage `st` of step d into ring slot `slot`
     auto dma_b = [&](const Step &d, int st, int slot) {
         const int soff = d.live ? ((d.nt * BN * 9 + st * TS) * a.Cin + d.c * CK) * 2 : 0;
-        if (HALO_DBG(2)) return;
+        if (HALO_DBG(2) || !is_loader) return;
 #pragma unroll
         for (int k = 0; k < PB; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr)(lds + BOFF + slot * STAGE + (wave + NW * k) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lds_ptr)(lds + BOFF + slot * STAGE + (wave + NL * k) * 1024), 16,
                                                      (int)voff_b[k], soff, 0, 0);
     };
 
@@ -225,7 +231,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
                 for (int r = 0; r < 4 * GW; ++r) acc[i][j][r] = 0.f;
     };
-    // fragment ring: reads run AH k-steps ahead of their MFMAs (a 16 x 16 x 32 step is as long as two 32 x 32 x 16 steps)
+    // fragment ring: reads run AH k-steps ahead of their MFMAs (a 16 x 16 x 32 step is as long as two 32 x 32 x 16 steps; two
+    // of them ahead measured 4 % fewer cycles per stage and +0.5 ... 1 % on the whole network, but needs 6-10 spilled registers)
     constexpr int RD = M16 ? 2 : 3, AH = RD - 1;
     struct Frag {
         bf16x8 a[FM], b[FN];
@@ -348,6 +355,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         }
     };
 
+    // developer timeline of wave 0 (dev build): cycles between the stamps, summed over the stages of the workgroup
+#ifdef TY1_DEV_STAMPS
+    const bool do_stamp = a.stamp != nullptr;
+#else
+    constexpr bool do_stamp = false;
+#endif
+    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, s_mma = 0, s_vm = 0, s_bar = 0, s_epi = 0, n_st = 0;
+    (void)tk0; (void)tk1; (void)tk2; (void)tk3; (void)tk4;
+    if (do_stamp && lane == 0) a.stamp[((long long)blockIdx.x * NW + wave) * 8 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+
     // ---- prologue: first halo, first weight stages
     int u = 0;
     Step cur = step_of(0);
@@ -389,9 +406,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
                 // fetch: one halo piece of the next step, then the weights three stages ahead (ring slot last read in stage st - 1)
                 auto fetch = [&] {
                     if (st < HPW) dma_halo(nxt, st, hbuf ^ 1);
+                    if (st + NSC < HPW) dma_halo(nxt, st + NSC, hbuf ^ 1);
                     if (st + 3 < NSC) dma_b(cur, st + 3, (gs + 3) & 3);
                     else dma_b(nxt, st + 3 - NSC, (gs + 3) & 3);
                 };
+                HALO_STAMP(tk0);
                 if (!late) fetch();
                 const unsigned boff_cur = (unsigned)((gs & 3) * STAGE), boff_nxt = (unsigned)(((gs + 1) & 3) * STAGE);
 #pragma unroll
@@ -405,15 +424,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
                 }
                 // the PB newest DMAs of this wave (stage st + 3) may stay in flight; everything older - stage st + 2, the
                 // halo piece, the stores of an epilogue a stage ago - has landed once the counter is down to PB
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+                HALO_STAMP(tk1);
+                if (is_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                HALO_STAMP(tk2);
                 if (st == 0) landed();
                 stage_barrier();
+                HALO_STAMP(tk3);
+                if (do_stamp) { s_mma += tk1 - tk0; s_vm += tk2 - tk1; s_bar += tk3 - tk2; ++n_st; }
                 ++gs;
             }
         }
         if (cur.c == nch - 1) {
+            HALO_STAMP(tk3);
             if (!HALO_DBG(8)) epilogue(cur);
             zero_acc();
+            HALO_STAMP(tk4);
+            if (do_stamp) s_epi += tk4 - tk3;
         }
         {
             const unsigned delta = hbuf ? (unsigned)-HALO1 : (unsigned)HALO1;
@@ -427,6 +454,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         ++u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+    if (do_stamp && lane == 0) {
+        long long *o = a.stamp + ((long long)blockIdx.x * NW + wave) * 8;
+        o[1] = s_mma; o[2] = s_vm; o[4] = s_bar; o[5] = s_epi; o[7] = n_st;
+        o[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 int num_cus_here() {       // cached per device id (one process may drive several GPUs)
@@ -439,7 +471,8 @@ int num_cus_here() {       // cached per device id (one process may drive severa
     return cus;
 }
 
-template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false>
+template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false,
+          int NL = WAVES_M * WAVES_N>
 int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     a.tiles_x = a.W / PW;
     a.tiles_y = a.H / PH;
@@ -450,7 +483,7 @@ int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     const long long want = (long long)per_cu * num_cus_here();
     const double px = (double)a.NB * a.H * a.W;
     ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
-    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI, FM, FN, M16>
+    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI, FM, FN, M16, NL>
         <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
     return ty1::check_launch(name);
 }
@@ -493,6 +526,9 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha;
     if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
+#ifdef TY1_DEV_STAMPS
+    a.stamp = ty1::g_stamp;
+#endif
     // every wave owns 64 x 64 of the tile as 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 (in-call A/Bs against 2 x 2 blocks of
     // 32x32x16: -1.5 ... -3 % per layer timed alone; whole bf16 network +5.4, +4.4, +0.4 and -1.5 % images/s on four devices)
     if (ty1::dev_env("TY1_HALO_M32")) {          // developer override: 2 x 2 blocks of 32x32x16
