@@ -40,10 +40,11 @@ _CFG = {'128x128': '2, 2, 2, 2, 32', '128x64': '2, 1, 2, 2, 32', '64x64': '1, 1,
 ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv3x3_c16_pool': 'conv3x3_c16_kernel<true, 1>',
                   'conv3x3_c3_pool_bf16out': 'conv3x3_c3p_kernel<true, 1, true>',
                   'conv3x3_c16_bf16_pool': 'conv3x3_c16_bf16_kernel<true, 1>',
-                  'conv_halo_bf16_c32': 'conv_halo_bf16_kernel<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true>',
-                  'conv_halo_bf16_8x28': 'conv_halo_bf16_kernel<64, 128, 4, 2, 8, 28, false, 1, 4, 4, true>',
-                  'conv_halo_bf16_14x14': 'conv_halo_bf16_kernel<64, 128, 4, 2, 14, 14, false, 1, 4, 4, true>',
-                  'conv_halo_bf16_4x7x7': 'conv_halo_bf16_kernel<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>',
+                  'conv_halo_bf16_c32': 'conv_halo_bf16_kernel<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true, 4, false>',
+                  'conv_halo_bf16_8x28': 'conv_halo_bf16_kernel<64, 128, 4, 2, 8, 28, false, 1, 4, 4, true, 8, false>',
+                  'conv_halo_bf16_14x14': 'conv_halo_bf16_kernel<64, 128, 4, 2, 14, 14, false, 1, 4, 4, true, 8, false>',
+                  'conv_halo_bf16_4x7x7': 'conv_halo_bf16_kernel<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, false>',
+                  'conv_halo_bf16_4x7x7_ksplit': 'conv_halo_bf16_kernel<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>',
                   'dense_f32_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2, 4>',
                   'dense_f32_32x128': 'dense_gemm_f32_kernel<1, 1, 1, 4, 4>',
                   'decode_nms': 'decode_nms_kernel<2>', 'head_activate': 'head_activate_kernel'}

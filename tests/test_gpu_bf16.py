@@ -105,6 +105,17 @@ def test_conv_block_bf16_halo_vs_oracle(N, H, cin, cout, pool):
     assert (got == bf16_round(ref)).mean() > 0.99
 
 
+@pytest.mark.parametrize('N', [128, 126])
+def test_conv_block_bf16_halo_k_slices_vs_oracle(N):
+    """7x7x1024->256 at the batch of configs[2]: 64 tiles for 256 CUs, so the halo kernel runs four K slices per tile into the
+    (NaN-poisoned) workspace and a second launch sums them; 126 images leave the last tile ragged."""
+    assert ops.conv3x3_workspace_bytes_bf16(N, 7, 7, 1024, 256, False) == ((N + 3) // 4) * 2 * 4 * 256 * 128 * 4
+    got, ref = _case(N, 7, 1024, 256, False, False, seed=11, use_ws=True)
+    err = np.abs(got - ref)
+    assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
+    assert (got == bf16_round(ref)).mean() > 0.99
+
+
 def test_cast_bf16_round_to_nearest_even():
     x = torch.randn(100003, device=DEV) * 37.0
     assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))

@@ -53,9 +53,10 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
                        int W, int Cout, int pool, float alpha, hipStream_t s);
 
 // conv_halo.hip
-int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool);
+int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool);     // 0 no, 1 yes, >= 2: yes with that many K slices
+size_t conv3x3_halo_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout, int pool);   // workspace of a K-sliced layer (else 0)
 int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
-                      int Cin, int Cout, int pool, float alpha, hipStream_t s);
+                      int Cin, int Cout, int pool, float alpha, float *ws, hipStream_t s);
 
 }  // namespace ty1
 

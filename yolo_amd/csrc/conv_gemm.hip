@@ -1099,10 +1099,16 @@ int conv3x3_dispatch_bf16(const void *x, const void *w, const float *scale, cons
     }
     TY1_REQUIRE(Cin % 32 == 0, "ty1_conv3x3_bf16: Cin=%d must be 3, 16 or a multiple of 32", Cin);
     TY1_REQUIRE((2ll * H * W + 2ll * (W + 1)) * Cin * 2 < (1ll << 31), "ty1_conv3x3_bf16: one image (%dx%dx%d) is too large for 32-bit offsets", H, W, Cin);
-    // layers with enough whole work items: input halo in LDS instead of im2col rows (conv_halo.hip); needs no workspace
+    // layers with enough whole work items: input halo in LDS instead of im2col rows (conv_halo.hip); only its K-sliced form
+    // (deep K, few tiles) wants a workspace
     if (!out_f32 && ty1::conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool) && !ty1::dev_env("TY1_NO_HALO")) {
-        if (ws_need) return 0;
-        return ty1::conv3x3_halo_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, s);
+        const size_t need = ty1::conv3x3_halo_bf16_ws_bytes(N, H, W, Cin, Cout, pool);
+        if (ws_need) {
+            *ws_need = need;
+            return 0;
+        }
+        if (need == 0 || (ws && ws_bytes >= need))        // (a K-sliced layer without its workspace runs on the implicit GEMM)
+            return ty1::conv3x3_halo_bf16(x, w, scale, shift, y, N, H, W, Cin, Cout, pool, alpha, ws, s);
     }
     ConvArgs a{};
     a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w); a.scale = scale; a.shift = shift;

@@ -40,6 +40,8 @@ struct HaloArgs {
     int NB, H, W, Cin, Cout;
     float alpha;
     int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
+    float *part;                                 // K-split instantiations: fp32 partial tiles [item][rows of the tile][BN]
+    int splits;                                  // ... an item is one of `splits` K slices of a (patch, channel tile)
     long long *stamp;                            // developer timeline (dev build only; 8 x i64 per wave, tools/stamp_trace.py --halo)
     int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered
 };
@@ -64,8 +66,10 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to n
 // 32 k) instead of 32 x 32 (v_mfma_f32_32x32x16_bf16, 32 rows x 16 k): the same reads, bytes and matrix cycles per FLOP, but
 // on random operands the chip holds a higher clock under the 16 x 16 shape (MI355X_MICROARCH.md, DVFS give-back item 7).
 // NL: the first NL waves of the workgroup issue all LDS-DMA (default: every wave its share).
+// KSPL (layers without a pool): an item reduces only Cin / splits channels and stores its raw fp32 accumulators as a partial
+// tile; halo_fixup_kernel sums the slices in a fixed order and applies BN + LeakyReLU (deep K with too few tiles for the chip).
 template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false,
-          int NL = WAVES_M * WAVES_N>
+          int NL = WAVES_M * WAVES_N, bool KSPL = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_halo_bf16_kernel(const HaloArgs a) {
     constexpr int BS = M16 ? 16 : 32;                                  // rows / columns of an accumulator block
     constexpr int KS = M16 ? 32 : 16, KSH = M16 ? 6 : 5;               // k per MFMA; log2 of its bytes in a row
@@ -108,7 +112,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const bool is_loader = NL == NW || wave < NL;
     const int G = gridDim.x;
-    const int nch = a.Cin / CK;
+    const int nch = KSPL ? a.Cin / CK / a.splits : a.Cin / CK;       // K chunks of one item
+    static_assert(!KSPL || (NI > 1 && !RES_B), "K split: layers without a pool, streamed weights");
     const int frag_row = lane & (BS - 1), h = lane / BS;               // row of a block, 16-byte k slot within an MFMA step
     const int Ho = a.H >> 1, Wo = a.W >> 1;
 
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 
     // ---- work: item = (patch, channel tile), channel tile fastest; a step = one K chunk of an item
     struct Step {
-        int img, y0, x0, nt, c;
+        int img, y0, x0, nt, c, cg, item;         // c: chunk within the item, cg: chunk within Cin
         bool live;
     };
     auto step_of = [&](int u) {
@@ -171,8 +176,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const int k = u / nch;
         const long long item = (long long)blockIdx.x + (long long)k * G;
         d.live = item < a.items;
-        const int it = d.live ? (int)item : 0;
+        const int it_all = d.live ? (int)item : 0;
+        const int sp = KSPL ? it_all % a.splits : 0, it = KSPL ? it_all / a.splits : it_all;      // K slice fastest
         d.c = u - k * nch;
+        d.cg = __builtin_amdgcn_readfirstlane(sp * nch + d.c);
+        d.item = __builtin_amdgcn_readfirstlane(it_all);
         d.nt = it % a.ntiles;
         const int patch = it / a.ntiles;
         const int tx = patch % a.tiles_x, r = patch / a.tiles_x;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(static_cast<const char *>(a.x)) + img_b - a_shift, 0,
             d.live ? NI * a.H * a.W * a.Cin * 2 + a_shift : 0, 0x00020000);
-        const int soff = ((d.y0 * a.W + d.x0) * a.Cin + d.c * CK) * 2;
+        const int soff = ((d.y0 * a.W + d.x0) * a.Cin + d.cg * CK) * 2;
         const int hy = hyx[k] & 0xFF, hx = (hyx[k] >> 8) & 0xFF, sub = hyx[k] >> 16;
         const bool ok = hyx[k] >= 0 && (unsigned)(d.y0 - 1 + hy) < (unsigned)a.H && (unsigned)(d.x0 - 1 + hx) < (unsigned)a.W &&
                         d.img + sub < a.NB;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     };
     // the PB weight pieces of this wave for stage `st` of step d into ring slot `slot`
     auto dma_b = [&](const Step &d, int st, int slot) {
-        const int soff = d.live ? ((d.nt * BN * 9 + st * TS) * a.Cin + d.c * CK) * 2 : 0;
+        const int soff = d.live ? ((d.nt * BN * 9 + st * TS) * a.Cin + d.cg * CK) * 2 : 0;
         if (HALO_DBG(2) || !is_loader) return;
 #pragma unroll
         for (int k = 0; k < PB; ++k)
@@ -312,6 +320,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
         for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));
     };
     auto epilogue = [&](const Step &d) {
+        if constexpr (KSPL) {
+            // raw accumulators of this K slice -> partial tile `item` (every row of the tile, padding rows included)
+            constexpr int TROWS = BS * FM * WAVES_M;
+            const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                a.part + (long long)d.item * TROWS * BN, 0, TROWS * BN * 4, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const unsigned vb = (unsigned)((wave_m * (BS * FM) + 4 * h) * BN + wave_n * (BS * FN) + BS * j + frag_row) * 4u;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4 * GW; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]), p_rsrc, (int)vb,
+                                                              (BS * i + (r & 3) + (M16 ? 0 : 8 * (r >> 2))) * BN * 4, 0);
+            }
+            return;
+        }
         if constexpr (!POOL) {
             // rows of the item are consecutive rows of the output; the resource ends behind the last image that exists,
             // so padding rows and images past the batch are dropped by the range check
@@ -471,21 +496,58 @@ int num_cus_here() {       // cached per device id (one process may drive severa
     return cus;
 }
 
+// y = LeakyReLU(scale * sum over the K slices + shift) for the partial tiles of a K-split launch (NI images of P pixels per
+// tile, rows in image order); slices are added in index order.  One thread per four channels of a row.
+template <int TROWS, int BN>
+__global__ __launch_bounds__(256) void halo_fixup_kernel(const float *__restrict__ part, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, unsigned short *__restrict__ y, int ntiles,
+                                                         int splits, int rows_per_tile, long long rows_total, int Cout, float alpha) {
+    const int tile = blockIdx.x, nt = tile % ntiles, group = tile / ntiles;
+    const int e = blockIdx.y * 256 + threadIdx.x, row = e / (BN / 4), c4 = (e - row * (BN / 4)) * 4;
+    const long long orow = (long long)group * rows_per_tile + row;
+    if (row >= rows_per_tile || orow >= rows_total) return;
+    const float4 *p = reinterpret_cast<const float4 *>(part + ((long long)tile * splits * TROWS + row) * BN + c4);
+    float4 v = p[0];
+    for (int sp = 1; sp < splits; ++sp) {
+        const float4 w = p[(long long)sp * TROWS * BN / 4];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const int n = nt * BN + c4;
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + n), sh = *reinterpret_cast<const float4 *>(shift + n);
+    float t[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w};
+    unsigned short o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = bf16_bits(t[q] > 0.f ? t[q] : t[q] * alpha);
+    *reinterpret_cast<uint2 *>(y + orow * Cout + n) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+}
+
 template <int CK, int BN, int WAVES_M, int WAVES_N, int PH, int PW, bool RES_B, int NI = 1, int FM = 2, int FN = 2, bool M16 = false,
-          int NL = WAVES_M * WAVES_N>
+          int NL = WAVES_M * WAVES_N, bool KSPL = false>
 int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     a.tiles_x = a.W / PW;
     a.tiles_y = a.H / PH;
     a.ntiles = a.Cout / BN;
-    const long long items = (long long)((a.NB + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.ntiles;
+    const long long items = (long long)((a.NB + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.ntiles * (KSPL ? a.splits : 1);
     TY1_REQUIRE(items < (1ll << 31), "ty1_conv3x3_bf16(halo): too many work items");
     a.items = (int)items;
     const long long want = (long long)per_cu * num_cus_here();
     const double px = (double)a.NB * a.H * a.W;
-    ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
-    conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI, FM, FN, M16, NL>
-        <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
-    return ty1::check_launch(name);
+    {
+        ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
+        conv_halo_bf16_kernel<CK, BN, WAVES_M, WAVES_N, PH, PW, RES_B, NI, FM, FN, M16, NL, KSPL>
+            <<<dim3((unsigned)(items < want ? items : want)), dim3(64 * WAVES_M * WAVES_N), 0, s>>>(a);
+        if (int rc = ty1::check_launch(name)) return rc;
+    }
+    if constexpr (KSPL) {
+        constexpr int TROWS = (M16 ? 16 : 32) * FM * WAVES_M;
+        const int tiles = (int)(items / a.splits);
+        ty1::ProfScope fix("conv_halo_fixup", s, 0.0, 4.0 * (double)items * TROWS * BN + 2.0 * px * a.Cout);
+        halo_fixup_kernel<TROWS, BN><<<dim3((unsigned)tiles, (unsigned)((NI * PH * PW * (BN / 4) + 255) / 256)), 256, 0, s>>>(
+            a.part, a.scale, a.shift, static_cast<unsigned short *>(a.y), a.ntiles, a.splits, NI * PH * PW, (long long)a.NB * PH * PW,
+            a.Cout, a.alpha);
+        return ty1::check_launch("conv_halo_fixup");
+    }
+    return 0;
 }
 
 }  // namespace
@@ -500,9 +562,14 @@ int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool
     if (!pool) {
         // 7x7 maps without a pool, four whole images per item: one item is Cin / 64 x 9 weight stages long, so only when
         // the items come in whole rounds of the chip (7x7x512->1024 at 128 images: 256 items)
-        if (H == 7 && W == 7 && Cin % 64 == 0 && Cin <= 512 && Cout % 128 == 0 && !ty1::dev_env("TY1_NO_HALO7")) {
+        if (H == 7 && W == 7 && Cin % 64 == 0 && Cout % 128 == 0 && !ty1::dev_env("TY1_NO_HALO7")) {
             const long long items = (long long)((N + 3) / 4) * (Cout / 128);
-            return items >= cus && items % cus == 0;
+            if (Cin <= 512) return items >= cus && items % cus == 0;
+            // deeper K with too few tiles for the chip (7x7x1024->256 at 128 images: 64): the items are K slices whose raw
+            // accumulators go to a workspace (conv3x3_halo_bf16_ws_bytes), a second launch sums them
+            if (Cin <= 2048 && !ty1::dev_env("TY1_NO_HALO7K"))
+                for (int sp = 2; sp <= 8; sp *= 2)
+                    if ((Cin / 64) % sp == 0 && Cin / 64 / sp >= 2 && (items * sp) % cus == 0) return sp;
         }
         return 0;
     }
@@ -519,8 +586,15 @@ int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool
     return 0;
 }
 
+// workspace bytes of a layer conv3x3_halo_bf16_supported() accepts (0: none needed)
+size_t conv3x3_halo_bf16_ws_bytes(int N, int H, int W, int Cin, int Cout, int pool) {
+    const int sp = conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool);
+    if (pool || sp < 2) return 0;
+    return (size_t)((N + 3) / 4) * (Cout / 128) * sp * 256 * 128 * sizeof(float);
+}
+
 int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const float *shift, void *y, int N, int H, int W,
-                      int Cin, int Cout, int pool, float alpha, hipStream_t s) {
+                      int Cin, int Cout, int pool, float alpha, float *ws, hipStream_t s) {
     HaloArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y;
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -531,11 +605,17 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
 #endif
     // every wave owns 64 x 64 of the tile as 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 (in-call A/Bs against 2 x 2 blocks of
     // 32x32x16: -1.5 ... -3 % per layer timed alone; whole bf16 network +5.4, +4.4, +0.4 and -1.5 % images/s on four devices)
-    if (ty1::dev_env("TY1_HALO_M32")) {          // developer override: 2 x 2 blocks of 32x32x16
+    if (ty1::dev_env("TY1_HALO_M32") && (pool || Cin <= 512)) {          // developer override: 2 x 2 blocks of 32x32x16
         if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
         if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
         if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
         return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+    }
+    if (!pool && Cin > 512) {
+        a.splits = conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool);
+        a.part = ws;
+        TY1_REQUIRE(a.splits >= 2 && ws, "ty1_conv3x3_bf16(halo): K-split layer without workspace");
+        return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>("conv_halo_bf16_4x7x7_ksplit", a, 1, s);
     }
     if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>("conv_halo_bf16_4x7x7", a, 1, s);
     if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true>("conv_halo_bf16_c32", a, 2, s);
