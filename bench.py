@@ -46,6 +46,7 @@ ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv
                   'conv_halo_bf16_4x7x7': 'conv_halo_bf16_kernel<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, false>',
                   'conv_halo_bf16_4x7x7_ksplit': 'conv_halo_bf16_kernel<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>',
                   'dense_f32_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2, 4>',
+                  'dense_bf16_64x64': 'dense_gemm_f32_kernel<1, 1, 2, 2, 2>',
                   'dense_f32_32x128': 'dense_gemm_f32_kernel<1, 1, 1, 4, 4>',
                   'decode_nms': 'decode_nms_kernel<2>', 'head_activate': 'head_activate_kernel'}
 for _k, _v in _CFG.items():

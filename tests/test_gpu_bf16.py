@@ -116,6 +116,22 @@ def test_conv_block_bf16_halo_k_slices_vs_oracle(N):
     assert (got == bf16_round(ref)).mean() > 0.99
 
 
+@pytest.mark.parametrize('N', [1, 33, 64, 70, 128, 130])
+def test_dense_splitk_bf16_vs_oracle(N):
+    """ty1_dense_splitk_bf16 at the batch sizes of its tile shapes (32 x 128 up to 32 rows, 64 x 64 above; ragged last row
+    tile at 33 / 70 / 130) against the oracle with the same rounding of features and weights; fp32 accumulation in a
+    different order: 2e-3 of the logits' RMS."""
+    rng = np.random.default_rng(N)
+    units = 1470
+    feats = rng.standard_normal((N, P.FEATURES)).astype(np.float32)
+    w = (0.02 * rng.standard_normal((P.FEATURES, units))).astype(np.float32)
+    z_ref = model_ref.dense_ref(feats, w, np.zeros(units, np.float32), bf16=True)
+    part = ops.dense_splitk(ops.cast_bf16(dev(feats)), ops.cast_bf16(dev(P.dense_to_device_layout(w))), units)
+    assert part.shape[0] == ops.pick_splits(P.FEATURES, N, units, chunk=64)
+    z = part.sum(0)[:, :units].cpu().numpy()
+    assert np.abs(z - z_ref).max() < 2e-3 * np.sqrt((z_ref ** 2).mean())
+
+
 def test_cast_bf16_round_to_nearest_even():
     x = torch.randn(100003, device=DEV) * 37.0
     assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))

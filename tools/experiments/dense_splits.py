@@ -7,7 +7,7 @@ from yolo_amd import ops  # noqa: E402
 
 dev = 'cuda:0'
 K, units = 12544, 1470
-cases = [(False, 1, 'infer'), (False, 1, 'fused'), (True, 1, 'infer'), (True, 1, 'fused'), (False, 4, 'infer'), (False, 4, 'fused'), (False, 8, 'infer'), (False, 8, 'fused'), (False, 16, 'infer'), (False, 32, 'train')]
+cases = [(True, 128, 'infer'), (False, 1, 'infer'), (False, 1, 'fused'), (True, 1, 'infer'), (True, 1, 'fused'), (False, 4, 'infer'), (False, 4, 'fused'), (False, 8, 'infer'), (False, 8, 'fused'), (False, 16, 'infer'), (False, 32, 'train')]
 if len(sys.argv) > 1:
     cases = [c for c in cases if c[2] in sys.argv[1:]]
 for bf, N, kind in cases:
@@ -18,7 +18,7 @@ for bf, N, kind in cases:
     yt = torch.zeros((N, 7, 7, 25), device=dev)
     chunk = 64 if bf else ops.DENSE_K_ALIGN
     default = ops.pick_splits(K, N, units, chunk=chunk)
-    for s in sorted({default, 14, 21, 28}):
+    for s in sorted({default, 7, 11, 14, 16, 21, 22, 28, 33, 44}):
         if s > K // chunk:
             continue
         part = torch.empty((s, N, 1472), device=dev)
