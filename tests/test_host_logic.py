@@ -278,3 +278,19 @@ def test_detection_records():
     assert recs[0]['box'] == (10.9 * 2, 20.2 * 0.5, 100.7 * 2, 200.99 * 0.5)
     lines = voc_result_lines('000012', recs)
     assert lines['person'] == ['000012 0.900000 21.8 10.1 201.4 100.5']
+
+
+def test_dense_split_choice():
+    """ops.pick_splits (host logic, no GPU): one block per CU for the 32 x 128 tiles of batches up to 32, two per CU for the
+    64 x 64 tiles above, never a K slice shorter than four chunks, never more blocks than one round of the chip."""
+    from yolo_amd import ops
+    K, units = P.FEATURES, 1470
+    for n in (1, 8, 32):
+        assert ops.pick_splits(K, n, units) == 21 and ops.pick_splits(K, n, units, chunk=64) == 21
+    assert ops.pick_splits(K, 64, units) == 22 and ops.pick_splits(K, 128, units, chunk=64) == 11
+    for n in (1, 33, 64, 65, 128, 200, 512, 4096):
+        for chunk in (ops.DENSE_K_ALIGN, 64):
+            s = ops.pick_splits(K, n, units, chunk=chunk)
+            tiles = ((n + 63) // 64) * ((units + 63) // 64) if n > 32 else (units + 127) // 128
+            assert s >= 1 and (s == 1 or (K // chunk) // s >= 4)
+            assert s == 1 or tiles * s <= (512 if n > 32 else 256)
