@@ -1,6 +1,6 @@
 // 3x3 conv + folded BN + LeakyReLU (+ 2x2 max-pool) blocks of the bf16 network on an LDS-resident input halo
 // (v_mfma_f32_16x16x32_bf16, 4 x 4 blocks per wave; /root/reference/models/model_tiny_yolov1.py:52-84, the blocks with
-// Cin = 32 ... 512).
+// Cin = 32 ... 1024).
 //
 // Why a second kernel next to conv_persist_kernel (conv_gemm.hip): that loop fetches a 128-byte row of A per output
 // pixel, tap and K chunk - the im2col matrix, every activation nine times - and in bf16 the fetch, not the matrix pipe,
@@ -58,7 +58,7 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {     // round to n
     return __builtin_bit_cast(unsigned short, hv);
 }
 
-// CK: channels per K chunk (32 or 64).  BN: output channels per item.  PH x PW: patch (even, PH * PW <= 64 * WAVES_M).
+// CK: channels per K chunk (32 or 64).  BN: output channels per item.  PH x PW: patch (even, at most as many pixels as the tile has rows).
 // RES_B: Cin == CK and Cout == BN - the whole weight tensor (9 x BN x CK) is loaded once and stays in LDS.
 // NI > 1 (layers without a pool, whole maps): an item is NI consecutive images of PH x PW = H x W pixels, each with its own
 // ring of zeros in LDS; GEMM rows in natural order (image, y, x), every accumulator is stored.
