@@ -43,7 +43,7 @@ struct HaloArgs {
     float *part;                                 // K-split instantiations: fp32 partial tiles [item][rows of the tile][BN]
     int splits;                                  // ... an item is one of `splits` K slices of a (patch, channel tile)
     long long *stamp;                            // developer timeline (dev build only; 8 x i64 per wave, tools/stamp_trace.py --halo)
-    int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered
+    int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered, 64 no fence between a step's fragment reads and its MFMAs
 };
 #ifdef TY1_DEV_STAMPS
 #define HALO_DBG(bit) ((a.dbg & (bit)) != 0)
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
 #pragma unroll
         for (int q = 0; q < STEPS; ++q) {
             if (q + AH < STEPS) read_frag(f[(q + AH) % RD], st * TS + (q + AH) / NS16, (q + AH) % NS16, slot, (q + AH) / NS16);
+            if (M16 && !HALO_DBG(64)) __builtin_amdgcn_sched_barrier(0);
             mfma(f[q % RD]);
         }
     };
@@ -444,6 +445,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
                     const int q = st * NS16 + ks, q2 = q + AH, st2 = q2 / NS16, s2 = q2 % NS16;
                     if (q2 < Q) read_stream(fr[q2 % RD], st2, s2, st2 == st ? boff_cur : boff_nxt, 0u);
                     else read_stream(fr[q2 % RD], st2 - NSC, s2, boff_nxt, hd_next);      // first k-steps of the next step
+                    // (without this fence hipcc lets the reads share registers with the fragments in use and issues them
+                    //  behind ten of the sixteen MFMAs: the next step then starts with an exposed LDS round trip)
+                    if (M16 && !HALO_DBG(64)) __builtin_amdgcn_sched_barrier(0);
                     mfma(fr[q % RD]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
