@@ -93,7 +93,9 @@ def test_conv_block_bf16_vs_oracle(N, H, cin, cout, pool, out_f32, use_ws):
 # work items per CU): weights resident (Cin = 32), streamed weights with one and with two K chunks and channel tiles
 HALO_CASES = [(44, 112, 32, 64, True), (80, 56, 64, 128, True), (40, 56, 128, 256, True),
               (64, 28, 128, 256, True), (128, 14, 256, 512, True),      # 14x14 patches: two and four K chunks and channel tiles
-              (126, 7, 512, 1024, False)]      # no pool, four whole 7x7 images per item; the last item holds two images
+              (126, 7, 512, 1024, False),
+              # the smallest batches the dispatcher still sends to these kernels (one round of the chip, or a bit less)
+              (16, 112, 32, 64, True), (16, 56, 64, 128, True), (32, 28, 128, 256, True), (64, 14, 256, 512, True)]      # no pool, four whole 7x7 images per item; the last item holds two images
 
 
 @pytest.mark.parametrize('N,H,cin,cout,pool', HALO_CASES)
@@ -105,12 +107,14 @@ def test_conv_block_bf16_halo_vs_oracle(N, H, cin, cout, pool):
     assert (got == bf16_round(ref)).mean() > 0.99
 
 
-@pytest.mark.parametrize('N', [128, 126])
-def test_conv_block_bf16_halo_k_slices_vs_oracle(N):
-    """7x7x1024->256 at the batch of configs[2]: 64 tiles for 256 CUs, so the halo kernel runs four K slices per tile into the
-    (NaN-poisoned) workspace and a second launch sums them; 126 images leave the last tile ragged."""
-    assert ops.conv3x3_workspace_bytes_bf16(N, 7, 7, 1024, 256, False) == ((N + 3) // 4) * 2 * 4 * 256 * 128 * 4
-    got, ref = _case(N, 7, 1024, 256, False, False, seed=11, use_ws=True)
+@pytest.mark.parametrize('N,cin,cout,slices', [(128, 1024, 256, 4), (126, 1024, 256, 4), (64, 512, 1024, 2), (32, 512, 1024, 4),
+                                               (62, 512, 1024, 2)])
+def test_conv_block_bf16_halo_k_slices_vs_oracle(N, cin, cout, slices):
+    """7x7 layers with fewer tiles than CUs (7x7x1024->256 at the batch of configs[2]: 64 tiles for 256 CUs): the halo kernel
+    runs `slices` K slices per tile into the (NaN-poisoned) workspace and a second launch sums them; 126 / 62 images leave
+    the last tile ragged."""
+    assert ops.conv3x3_workspace_bytes_bf16(N, 7, 7, cin, cout, False) == ((N + 3) // 4) * (cout // 128) * slices * 256 * 128 * 4
+    got, ref = _case(N, 7, cin, cout, False, False, seed=11, use_ws=True)
     err = np.abs(got - ref)
     assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
     assert (got == bf16_round(ref)).mean() > 0.99

@@ -563,29 +563,31 @@ namespace ty1 {
 int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool) {
     if ((long long)4 * H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return 0;
     const long long cus = num_cus_here();
+    const bool force = ty1::dev_env("TY1_HALO_FORCE") != nullptr;     // developer sweep: every shape the kernels can run
     if (!pool) {
         // 7x7 maps without a pool, four whole images per item: one item is Cin / 64 x 9 weight stages long, so only when
         // the items come in whole rounds of the chip (7x7x512->1024 at 128 images: 256 items)
         if (H == 7 && W == 7 && Cin % 64 == 0 && Cout % 128 == 0 && !ty1::dev_env("TY1_NO_HALO7")) {
             const long long items = (long long)((N + 3) / 4) * (Cout / 128);
-            if (Cin <= 512) return items >= cus && items % cus == 0;
-            // deeper K with too few tiles for the chip (7x7x1024->256 at 128 images: 64): the items are K slices whose raw
-            // accumulators go to a workspace (conv3x3_halo_bf16_ws_bytes), a second launch sums them
-            if (Cin <= 2048 && !ty1::dev_env("TY1_NO_HALO7K"))
+            if (items >= cus) return Cin <= 512 && (force || items % cus == 0);
+            // too few tiles for the chip (7x7x1024->256 at 128 images: 64, 7x7x512->1024 at 64 images: 128): the items are K
+            // slices whose raw accumulators go to a workspace (conv3x3_halo_bf16_ws_bytes), a second launch sums them
+            if (Cin >= 512 && Cin <= 2048 && !ty1::dev_env("TY1_NO_HALO7K"))
                 for (int sp = 2; sp <= 8; sp *= 2)
-                    if ((Cin / 64) % sp == 0 && Cin / 64 / sp >= 2 && (items * sp) % cus == 0) return sp;
+                    if ((Cin / 64) % sp == 0 && Cin / 64 / sp >= 2 && ((items * sp) % cus == 0 || (force && items * sp >= cus))) return sp;
         }
         return 0;
     }
-    if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return (long long)N * (H / 16) * (W / 16) >= 8 * cus;
+    // item-count thresholds: tools/experiments/halo_batch_sweep.sh (16 ... 256 images, every shape forced vs the implicit GEMM)
+    if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return force || (long long)N * (H / 16) * (W / 16) >= 3 * cus;
     if ((Cin == 64 || Cin == 128) && Cout % 128 == 0 && H % 8 == 0 && W % 28 == 0)      // one or two K chunks: what the tests cover
-        return (long long)N * (H / 8) * (W / 28) * (Cout / 128) >= 4 * cus;
+        return force || (long long)N * (H / 8) * (W / 28) * (Cout / 128) * 4 >= 3 * cus;
     // 28x28 / 14x14 maps: 14x14 patches (196 pixels of a 256-row tile: a quarter of the rows is padding, and the kernel is
-    // still 16-25 % faster than the im2col loop) - but an item is 18-36 weight stages long, so only when the items come
-    // in whole rounds of the chip or there are many of them
+    // still 5-27 % faster than the im2col loop) - but an item is 18-36 weight stages long, so only when the items come
+    // in whole rounds of the chip (one round is enough) or there are many of them
     if ((Cin == 128 || Cin == 256) && Cout % 128 == 0 && H % 14 == 0 && W % 14 == 0 && !ty1::dev_env("TY1_NO_HALO14")) {
         const long long items = (long long)N * (H / 14) * (W / 14) * (Cout / 128);
-        return items >= 2 * cus && (items % cus == 0 || items >= 8 * cus);
+        return force || (items >= cus && (items % cus == 0 || items >= 8 * cus));
     }
     return 0;
 }
@@ -607,18 +609,19 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
 #ifdef TY1_DEV_STAMPS
     a.stamp = ty1::g_stamp;
 #endif
+    const int slices = pool ? 1 : conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool);
     // every wave owns 64 x 64 of the tile as 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 (in-call A/Bs against 2 x 2 blocks of
     // 32x32x16: -1.5 ... -3 % per layer timed alone; whole bf16 network +5.4, +4.4, +0.4 and -1.5 % images/s on four devices)
-    if (ty1::dev_env("TY1_HALO_M32") && (pool || Cin <= 512)) {          // developer override: 2 x 2 blocks of 32x32x16
+    if (ty1::dev_env("TY1_HALO_M32") && slices < 2) {          // developer override: 2 x 2 blocks of 32x32x16
         if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
         if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
         if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
         return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
     }
-    if (!pool && Cin > 512) {
-        a.splits = conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool);
+    if (slices >= 2) {
+        a.splits = slices;
         a.part = ws;
-        TY1_REQUIRE(a.splits >= 2 && ws, "ty1_conv3x3_bf16(halo): K-split layer without workspace");
+        TY1_REQUIRE(ws, "ty1_conv3x3_bf16(halo): K-sliced layer without workspace");
         return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>("conv_halo_bf16_4x7x7_ksplit", a, 1, s);
     }
     if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>("conv_halo_bf16_4x7x7", a, 1, s);
