@@ -114,10 +114,11 @@ def test_conv_block_bf16_halo_k_slices_vs_oracle(N, cin, cout, slices):
     runs `slices` K slices per tile into the (NaN-poisoned) workspace and a second launch sums them; 126 / 62 images leave
     the last tile ragged."""
     assert ops.conv3x3_workspace_bytes_bf16(N, 7, 7, cin, cout, False) == ((N + 3) // 4) * (cout // 128) * slices * 256 * 128 * 4
-    got, ref = _case(N, 7, cin, cout, False, False, seed=11, use_ws=True)
-    err = np.abs(got - ref)
-    assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
-    assert (got == bf16_round(ref)).mean() > 0.99
+    for use_ws in (True, False):          # without the workspace the layer falls back to the implicit GEMM
+        got, ref = _case(N, 7, cin, cout, False, False, seed=11, use_ws=use_ws)
+        err = np.abs(got - ref)
+        assert (err <= 2.0 ** -8 * np.abs(ref) + 2e-3).all(), float(err.max())
+        assert (got == bf16_round(ref)).mean() > 0.99
 
 
 @pytest.mark.parametrize('N', [1, 33, 64, 70, 128, 130])
