@@ -454,6 +454,16 @@ constexpr int C3_V4 = 50;                                    // float4 per halo 
 constexpr int C3_TILE = (C3_TH + 2) * C3_ROW;                // floats of one halo buffer
 constexpr int C3_ONES = 592;                                 // floats of 1.0 behind it (>= 2 * C3_ROW + 24 * 7 + 1), see FOLD
 constexpr int C3_BUF = C3_TILE + C3_ONES;
+// bf16 variant: which tap (k = 9 kh + 3 kw + ci) lane quarter kq supplies in slot e of the one K = 32 MFMA; -1 - offset: a zero-
+// weight pad that reads the LDS float at `offset` from the pixel's first tap.  With k = 8 kq + e a 32-lane half of every
+// A read hit 8 banks twice (SQ_LDS_BANK_CONFLICT 47 % of the LDS cycles, LDS instructions waiting 30 % of the wave cycles);
+// this assignment, found by search over a model of the 32 banks that reproduces that figure, has no conflict (first layer of
+// the bf16 network 117 -> 107 us alone, whole network +0.9 ... 3.6 %).  The same search for the f32 variant (26 -> 15 passes per
+// 14 reads) made that kernel 1-2 % slower - there the LDS is busy 31 % of the time and the MFMA issue is the bound - not kept.
+__device__ constexpr short C3_TAP_BF16[4][8] = {{22, 13, 0, 12, 20, 3, 16, 14},
+                                                {19, 10, 8, 15, 26, 6, -1 - (C3_ROW + 1), 11},
+                                                {21, 4, 17, 2, -1 - (2 * C3_ROW + 2), 18, 1, 25},
+                                                {24, -1 - 4, 9, 5, 23, -1 - (C3_ROW + 8), 7, -1 - (2 * C3_ROW + 7)}};
 
 template <bool POOL, int NT, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restrict__ x, const float *__restrict__ w,
@@ -482,10 +492,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
 
     // f32 (exact):  7 x v_mfma_f32_16x16x4_f32 per 16-pixel tile, lane quarter kq supplies k = 4*ks + kq of step ks.
     // OUT_BF16 (first layer of the bf16 network): image and weights are rounded to bf16 on the fly and a tile is
-    //               ONE v_mfma_f32_16x16x32_bf16, lane quarter kq supplies k = 8*kq .. 8*kq + 7.
-    // k = 27 .. 31 is the zero pad (weight 0, any valid LDS address).
+    //               ONE v_mfma_f32_16x16x32_bf16, lane quarter kq supplies the eight taps C3_TAP_BF16[kq][..]
+    //               (five of the 32 slots are zero pads: weight 0, a valid LDS address).
     constexpr int KS = OUT_BF16 ? 8 : 7;
-    auto k_of = [&](int ks) { return OUT_BF16 ? 8 * kq + ks : 4 * ks + kq; };
+    // (bf16: a tap, or >= 27 for a pad; its LDS offset comes from the table)
+    auto k_of = [&](int ks) { return OUT_BF16 ? (C3_TAP_BF16[kq][ks] >= 0 ? (int)C3_TAP_BF16[kq][ks] : 28) : 4 * ks + kq; };
     float wreg[NT][KS];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
     for (int ks = 0; ks < KS; ++ks) {
         const int k = k_of(ks);
         const int kh = k / 9;
-        koff[ks] = k < 27 ? kh * C3_ROW + (k - 9 * kh) : 0;
+        koff[ks] = k < 27 ? kh * C3_ROW + (k - 9 * kh) : (OUT_BF16 ? -1 - (int)C3_TAP_BF16[kq][ks] : 0);
     }
     float sc[NT], sh[NT];
 #pragma unroll
