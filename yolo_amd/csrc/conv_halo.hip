@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <type_traits>
 
 namespace {
@@ -42,6 +43,7 @@ struct HaloArgs {
     int tiles_x, tiles_y, ntiles, items;         // patches per image row / column, channel tiles, work items
     float *part;                                 // K-split instantiations: fp32 partial tiles [item][rows of the tile][BN]
     int splits;                                  // ... an item is one of `splits` K slices of a (patch, channel tile)
+    int key_a, key_c;                            // developer sweep of the halo swizzle key (dev build only; -1: the compiled-in pair)
     long long *stamp;                            // developer timeline (dev build only; 8 x i64 per wave, tools/stamp_trace.py --halo)
     int dbg;                                     // developer knock-outs (dev build only): 1 no halo fetch, 2 no weight fetch, 4 no barriers, 8 no epilogue, 16 DMA issue of the two waves of a SIMD staggered, 64 no fence between a step's fragment reads and its MFMAs
 };
@@ -91,6 +93,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     constexpr int KC = (CK == 32 && PW == 16) ? 1 : (CK == 32 && PW == 14) ? 2 : PW == 28 ? 5 : PW == 14 ? 4 : PW == 7 ? 7 : 0;
     auto key_px = [&](int hp) {
         const int row = hp / HWD;
+#ifdef TY1_DEV_STAMPS
+        if (a.key_a >= 0) return ((hp + a.key_a * row) / RPW + a.key_c * row) & (NSLOT - 1);
+#endif
         return ((hp + KA * row) / RPW + KC * row) & (NSLOT - 1);
     };
     constexpr int HP = (HPIX + PIXPP - 1) / PIXPP;                     // halo pieces
@@ -606,6 +611,8 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
     a.NB = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.alpha = alpha;
     if (const char *e = ty1::dev_env("TY1_HALO_DBG")) a.dbg = atoi(e);
+    a.key_a = a.key_c = -1;
+    if (const char *e = ty1::dev_env("TY1_HALO_KEY")) sscanf(e, "%d,%d", &a.key_a, &a.key_c);
 #ifdef TY1_DEV_STAMPS
     a.stamp = ty1::g_stamp;
 #endif
