@@ -229,6 +229,8 @@ int dense_dispatch(const void *x, const void *wt, float *part, int N, int K, int
     }
     a.ntiles = (units + 63) / 64;
     // (bf16 above 64 rows on 128 x 64 tiles: GEMM + tail 39.3 -> 35.5 us alone, nothing on the whole network: not kept)
+    // (four chunks in flight in registers instead of one, bf16: 39.6 vs 39.5 us - the two resident workgroups per CU already
+    //  cover the fetch latency: not kept)
     return launch_dense<1, 1, 2, 2, ESZ>(ESZ == 4 ? "dense_f32_64x64" : "dense_bf16_64x64", a, (N + 63) / 64, s);
 }
 
