@@ -122,11 +122,12 @@ def settle(ctx, step, settle_ms, est_step_ms):
             step()
     else:
         t0 = time.perf_counter()
+        burst = max(1, min(10, int(20.0 / max(est_step_ms, 0.05))))     # (a configs[4] step is ~100 ms: one at a time)
         while (time.perf_counter() - t0) * 1e3 < settle_ms and n < 4000:
-            for _ in range(10):
+            for _ in range(burst):
                 step()
             torch.cuda.synchronize(ctx.dev)
-            n += 10
+            n += burst
     ctx.sync()
     return n
 
@@ -247,16 +248,50 @@ def synthetic_images(n, seed, dev):
     return torch.rand((n, 448, 448, 3), generator=torch.Generator(device='cpu').manual_seed(seed))
 
 
-def run_infer(ctx, args, dtype, N, detailed=True):
+def nms_only(ctx, N, C, steps):
+    """Decode + threshold + NMS alone on predictions drawn directly (seed 2: class = 1 for C = 1, confidence and
+    box ~ U(0,1): dense candidates) - the "dense-box NMS stress test" half of configs[4]."""
+    from yolo_amd import ops
+    rng = np.random.default_rng(2)
+    p = np.empty((N, 7, 7, C + 10), np.float32)
+    if C > 1:
+        z = 4 * rng.random((N, 7, 7, C))
+        e = np.exp(z - z.max(-1, keepdims=True))
+        p[..., :C] = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    else:
+        p[..., :C] = 1.0
+    p[..., C:] = rng.random((N, 7, 7, 10)).astype(np.float32)
+    pd = torch.from_numpy(p).to(ctx.dev)
+    out = ops.decode_nms(pd, 2, C, 448)
+    for _ in range(3):
+        ops.decode_nms(pd, 2, C, 448, out=out)
+    torch.cuda.synchronize(ctx.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ops.decode_nms(pd, 2, C, 448, out=out)
+    e1.record()
+    torch.cuda.synchronize(ctx.dev)
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    nbytes = N * (49 * (C + 10) * 4 + 98 * (32 + 4 + 4 + 1))           # SURVEY 8d: prediction in, fixed-size records out
+    return {'us_per_launch': round(us, 1), 'images_per_sec': round(N / us * 1e6), 'kept_boxes_per_image': round(float(out[3].sum().item()) / N, 2),
+            'algo_bytes_per_launch': nbytes, 'algo_GBps': round(nbytes / us / 1e3, 1), 'frac_of_hbm_peak': round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4),
+            'note': 'one wavefront per image, up to 98 dependent greedy rounds: latency-bound, not bandwidth-bound'}
+
+
+def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
+    """C = 20: configs[1] / configs[2].  C = 1 (configs[4]): Dense 539 -> (7,7,11) head on the same backbone."""
     from yolo_amd import ops, params as P
     from yolo_amd.engine import DeviceModel
-    C = 20
     detailed = detailed and not args.graph      # a replayed graph has no per-launch brackets: no kernel table / roofline
-    C = 20
     prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
     model = DeviceModel(prm, C=C, device=ctx.dev, dtype=dtype)
-    x_cpu = synthetic_images(N, 0, ctx.dev)
-    x = x_cpu.to(ctx.dev)
+    if images_on_device:       # 4096 images are 9.9 GB: drawn on the device (torch's Philox generator), no host copy
+        x_cpu = None
+        x = torch.rand((N, 448, 448, 3), device=ctx.dev, generator=torch.Generator(device=ctx.dev).manual_seed(0))
+    else:
+        x_cpu = synthetic_images(N, 0, ctx.dev)
+        x = x_cpu.to(ctx.dev)
     model.workspace(N)
     if args.graph:                     # the batch lives in the graph's input buffer (no copy per step)
         xin = model.input_buffer(N)
@@ -288,7 +323,8 @@ def run_infer(ctx, args, dtype, N, detailed=True):
         'value': round(world * N * K / m['elapsed'], 1), 'unit': 'images/sec',
         'ms_per_step': round(1e3 * m['elapsed'] / K, 4), 'settle_steps': m['settle_steps'],
         'dtype': dtype,
-        'config': {'workload': (f'configs[1]: tiny-YOLOv1 448x448 batch={N}/GPU fp32' if dtype == 'f32' else
+        'config': {'workload': (f'configs[4]: single-class (C=1, Dense 539) tiny-YOLOv1 448x448 batch={N}/GPU fp32' if C == 1 else
+                                f'configs[1]: tiny-YOLOv1 448x448 batch={N}/GPU fp32' if dtype == 'f32' else
                                 f'configs[2]: tiny-YOLOv1 448x448 batch={N}/GPU bf16 (conv + Dense operands bf16, fp32 accumulate)')
                                + ' backbone+Dense+head+decode+NMS, random-init weights (glorot, identity BN: dense-candidate '
                                  'NMS stress), torch.rand images resident in HBM',
@@ -478,8 +514,19 @@ def main():
         also = {}
         sub = argparse.Namespace(**vars(args))
         sub.steps, sub.warmup, sub.settle_ms = min(args.steps, 50), min(args.warmup, 10), min(args.settle_ms, 100.0)
-        for key, fn in (('configs[2] bf16 inference', lambda: run_infer(ctx, sub, 'bf16', 128)[0]),
-                        ('configs[3] training step', lambda: run_train(ctx, sub, 32))):
+        big = argparse.Namespace(**vars(sub))      # a configs[4] step is 4096 images (~0.1 s): fewer of them
+        big.steps, big.warmup = min(args.steps, 5), min(args.warmup, 2)
+
+        def config4():
+            r = run_infer(ctx, big, 'f32', 4096, C=1, images_on_device=True)[0]
+            r['decode_nms_only'] = nms_only(ctx, 4096, 1, 20)
+            return r
+
+        legs = [('configs[2] bf16 inference', sub, lambda: run_infer(ctx, sub, 'bf16', 128)[0]),
+                ('configs[3] training step', sub, lambda: run_train(ctx, sub, 32))]
+        if ctx.world == 1:                         # a single-GPU configuration: kept out of the N > 1 scaling runs
+            legs.append(('configs[4] single-class batch 4096', big, config4))
+        for key, leg_args, fn in legs:
             if ctx.multi and ctx.backend != 'nccl' and 'training' in key:
                 # the rehearsal backend stalls in gloo's device-tensor all-reduce of the 74 MB bucket when two ranks share a
                 # card; the two-rank training step itself is covered by tests/test_gpu_ddp.py
@@ -488,7 +535,7 @@ def main():
             torch.cuda.empty_cache()
             r = fn()
             r.pop('kernels', None)
-            r['steps'], r['warmup'] = sub.steps, sub.warmup
+            r['steps'], r['warmup'] = leg_args.steps, leg_args.warmup
             also[key] = r
         out['also'] = also
     if ctx.rank == 0:
