@@ -376,8 +376,25 @@ def run_train(ctx, args, N, detailed=True):
         tr.update_after_layer = None if args.update_after_layer < 0 else args.update_after_layer
     state = {}
 
+    trace = os.environ.get('TY1_BENCH_TRACE')          # developer aid: one stderr line per training step (rank, index, host time)
+    t_start = time.perf_counter()
+    if trace and os.environ.get('TY1_BENCH_WATCHDOG'):  # ... and which stream / event is still pending when a run stalls
+        import threading
+
+        def probe():
+            cur = torch.cuda.current_stream(ctx.dev)
+            while True:
+                time.sleep(float(os.environ['TY1_BENCH_WATCHDOG']) / 2)
+                print(f'[rank {ctx.rank}] probe at {time.perf_counter() - t_start:.1f} s: step {state.get("i", 0)} compute stream idle={cur.query()} '
+                      f'side stream idle={tr.side.query() if tr.side else None} grads_ready={tr._grads_ready.query()} '
+                      f'updated={tr._updated.query()} pending={tr._pending} adam_deferred={tr._adam_deferred}', file=sys.stderr, flush=True)
+        threading.Thread(target=probe, daemon=True).start()
+
     def step():
         state['loss'] = tr.step(x, yd, wait=False)     # exchange + Adam stay in flight under the next backbone
+        if trace:
+            state['i'] = state.get('i', 0) + 1
+            print(f'[rank {ctx.rank}] train step {state["i"]} done at {time.perf_counter() - t_start:.3f} s', file=sys.stderr, flush=True)
 
     tr.bucket.always = ctx.multi                       # --force-gather: the collective runs on one rank too
     real_sync = ctx.sync

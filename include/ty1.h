@@ -81,6 +81,15 @@ int ty1_conv3x3_bn_leaky_ws_f32(const float *x, const float *w, const float *sca
  * written by the same call.
  */
 size_t ty1_static_scratch_bytes(void);
+/*
+ * Optional set-up of the entry point below on the CURRENT device: resolves the device address of the static scratch array
+ * (hipGetSymbolAddress) so that the first compute call does not have to.  Call it once per device outside any HIP graph
+ * capture; without it the first ty1_conv3x3_bn_leaky_static_f32 call on a device does the same work itself (also not
+ * capturable: make one eager call per device and tile configuration before capturing, as with any HIP library whose
+ * first launch loads its code object).  The 16 MiB array is part of libty1's code object: every process that loads the
+ * library pays it on every GPU it touches, whether or not it uses this entry point.
+ */
+int ty1_static_scratch_init(void);
 int ty1_conv3x3_bn_leaky_static_f32(const float *x, const float *w, const float *scale, const float *shift,
                                     float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,
                                     ty1_stream_t stream);
@@ -253,6 +262,18 @@ int ty1_dense_wgrad_f32(const float *dz, const float *x, float *dwt, float *db, 
  */
 int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1,
                       float beta2, float eps, int64_t t, ty1_stream_t stream);
+
+/*
+ * Room for a collective next to the persistent kernels.  No counterpart in the reference (it has no second device).
+ * Every persistent launch of the library (conv blocks in fp32 and bf16) sizes its grid to the workgroups that stay
+ * resident on (CU count - k) compute units; k = 0 (the default) fills the chip.  engine.Trainer can set k > 0 while its
+ * gradient all-reduce is in flight on a side stream, so that RCCL's workgroups find free CUs instead of queueing behind
+ * ~220 us conv kernels.  Only the number of workgroups changes - the work items, the K-split plan and every order of
+ * summation are made for the full CU count - so results are bit-identical for every k.  Process-wide, read at launch
+ * time on the host; at least 8 CUs are always used.
+ */
+int ty1_set_reserved_cus(int k);
+int ty1_get_reserved_cus(int *k);
 
 /*
  * Per-kernel device timing with HIP events recorded on the launch stream (used by bench.py

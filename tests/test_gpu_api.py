@@ -167,6 +167,121 @@ def test_training_step_vs_torch_reference_and_sharded_sum():
     assert losses[2] < losses[0]                                     # it learns
 
 
+def test_training_step_at_the_configured_batch_of_32():
+    """BASELINE configs[3] at its size (/root/reference/train.py:21,59-60: 32 images per GPU), where the launch shapes
+    differ from the small cases above (other conv tile plans, 21 Dense splits on 32 x 128 tiles, train_tail_kernel with
+    32 workgroups, the wgrad reduction over 32 rows).  Size-independent properties: two overlapped steps are
+    deterministic (loss and weights, bit for bit, against a second trainer built from the same parameters), dz of three
+    images against the fp32 torch restatement of Dense -> head -> yolo_loss, and the shard sum 20 + 12 = full batch."""
+    N, C = 32, 20
+    prm = P.make_random_params(seed=6, dense_init='glorot', bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(31)).to(DEV)
+    y_true = _labels(N, C, 32)
+    yd = torch.from_numpy(y_true).to(DEV)
+
+    def two_steps():
+        model = DeviceModel(prm, device=DEV)
+        tr = Trainer(model, lr=1e-5, overlap=True)
+        losses = [tr.step(x, yd, wait=False) for _ in range(2)]
+        tr.join()
+        torch.cuda.synchronize()
+        return model, tr, torch.cat(losses).cpu(), tr.pflat.clone().cpu(), tr.m.clone().cpu()
+
+    model, tr, losses, w, m = two_steps()
+    _, _, losses2, w2, m2 = two_steps()
+    assert torch.isfinite(losses).all() and torch.equal(losses, losses2) and torch.equal(w, w2) and torch.equal(m, m2)
+    assert losses[1] < losses[0]                                       # it learns
+
+    # dz of three images: GPU features (checked against the oracle elsewhere) -> torch fp32 Dense + head + yolo_loss
+    feats = model.backbone(x)
+    tr.gradients_from_features(feats, yd)
+    dz = tr._dz[N].cpu().numpy()[:, :model.units]
+    pick = [0, 13, 31]
+    wt = P.dense_from_device_layout(model.dense_wt.cpu().numpy(), model.units)
+    z = (torch.from_numpy(feats[pick].cpu().numpy()) @ torch.from_numpy(wt) + model.dense_b.cpu()).requires_grad_(True)
+    n = len(pick)
+    y = torch.cat([torch.softmax(z[:, :49 * C].reshape(n, 7, 7, C), -1), torch.sigmoid(z[:, 49 * C:49 * C + 98].reshape(n, 7, 7, 2)),
+                   torch.sigmoid(z[:, 49 * C + 98:].reshape(n, 7, 7, 8))], -1)
+    loss_ref.yolo_loss_ref(torch.from_numpy(y_true[pick]), y, C).backward()
+    dz_ref = z.grad.numpy()
+    # (fp32 bar: the logits themselves carry ~1e-5 relative rounding from the 12544-long dot products)
+    np.testing.assert_allclose(dz[pick], dz_ref, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(dz_ref).max()))
+
+    # shard sum (what the SUM all-reduce does, SURVEY Q12): 20 + 12 images on the full batch's features
+    full_dw, full_db, full_loss = tr.dwt.clone(), tr.db.clone(), tr.bucket.loss.clone()
+    la = tr.gradients_from_features(feats[:20].contiguous(), yd[:20].contiguous()).clone()
+    dw_a, db_a = tr.dwt.clone(), tr.db.clone()
+    lb = tr.gradients_from_features(feats[20:].contiguous(), yd[20:].contiguous()).clone()
+    torch.testing.assert_close(dw_a + tr.dwt, full_dw, rtol=1e-4, atol=1e-6 * max(1.0, full_dw.abs().max().item()))
+    torch.testing.assert_close(db_a + tr.db, full_db, rtol=1e-4, atol=1e-6 * max(1.0, full_db.abs().max().item()))
+    assert abs(la.item() + lb.item() - full_loss.item()) <= 1e-5 * abs(full_loss.item())
+
+
+def test_reserved_cus_change_grids_not_results():
+    """ty1_set_reserved_cus(k): every persistent grid is sized for (CUs - k) compute units - room for a collective's
+    workgroups next to them - while work items, K-split plans and summation orders stay those of the full chip, so every
+    output is bit-identical for every k: single layers of each kernel family (fp32 and bf16, with K-split tails), the
+    whole detect() in both arithmetics, and three overlapped training steps with Trainer.reserve_cus."""
+    from test_gpu_parity import dev
+    rng = np.random.default_rng(21)
+    assert ops.get_reserved_cus() == 0
+
+    def layer(N, H, cin, cout, pool, bf16):
+        x = dev(rng.random((N, H, H, cin)).astype(np.float32))
+        w = dev(P.hwio_to_ohwi(P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)))
+        sc, sh = dev(rng.uniform(0.5, 1.5, cout).astype(np.float32)), dev(rng.uniform(-0.5, 0.5, cout).astype(np.float32))
+        if bf16:
+            need = ops.conv3x3_workspace_bytes_bf16(N, H, H, cin, cout, pool)
+            if cin != 3:
+                x, w = ops.cast_bf16(x), ops.cast_bf16(w)
+            run = lambda: ops.conv3x3_bn_leaky_bf16(x, w, sc, sh, pool, workspace=torch.empty(max(need, 16), dtype=torch.uint8, device=DEV))
+        else:
+            need = ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool)
+            run = lambda: ops.conv3x3_bn_leaky(x, w, sc, sh, pool, workspace=torch.empty(max(need, 16), dtype=torch.uint8, device=DEV))
+        return run
+
+    try:
+        cases = [(4, 448, 3, 16, True, False), (4, 224, 16, 32, True, False), (24, 28, 128, 256, True, False), (12, 7, 1024, 256, False, False),
+                 (8, 112, 32, 64, True, False), (4, 448, 3, 16, True, True), (4, 224, 16, 32, True, True), (44, 112, 32, 64, True, True),
+                 (80, 56, 64, 128, True, True), (64, 28, 128, 256, True, True), (128, 7, 1024, 256, False, True), (24, 28, 128, 256, True, True)]
+        for case in cases:
+            run = layer(*case)
+            ops.set_reserved_cus(0)
+            want = run()
+            for k in (1, 37, 250, 100000):
+                ops.set_reserved_cus(k)
+                assert ops.get_reserved_cus() == k
+                assert torch.equal(run(), want), (case, k)
+        prm = P.make_random_params(seed=1, dense_init='spread', bn='random')
+        x = torch.rand((16, 448, 448, 3), generator=torch.Generator().manual_seed(5)).to(DEV)
+        for dtype in ('f32', 'bf16'):
+            model = DeviceModel(prm, device=DEV, dtype=dtype)
+            ops.set_reserved_cus(0)
+            want = [t.clone() for t in model.detect(x)]
+            ops.set_reserved_cus(48)
+            assert all(torch.equal(a, b) for a, b in zip(model.detect(x), want)), dtype
+        ops.set_reserved_cus(0)
+        # the trainer's use: the next batch's backbone runs on a shrunk grid while the update is in flight
+        prm = P.make_random_params(seed=6, dense_init='glorot', bn='random')
+        xs = [torch.rand((8, 448, 448, 3), generator=torch.Generator().manual_seed(40 + i)).to(DEV) for i in range(3)]
+        ys = [torch.from_numpy(_labels(8, 20, 50 + i)).to(DEV) for i in range(3)]
+        res = {}
+        for k in (0, 32):
+            model = DeviceModel(prm, device=DEV)
+            tr = Trainer(model, lr=1e-5, overlap=True)
+            tr.reserve_cus = k
+            losses = [tr.step(a, b, wait=False) for a, b in zip(xs, ys)]
+            tr.join()
+            torch.cuda.synchronize()
+            assert ops.get_reserved_cus() == 0            # the trainer restores the full chip after each backbone
+            res[k] = (torch.cat(losses).cpu(), tr.pflat.clone().cpu())
+        assert torch.equal(res[0][0], res[32][0]) and torch.equal(res[0][1], res[32][1])
+    finally:
+        ops.set_reserved_cus(0)
+    with pytest.raises(Exception, match='must be >= 0'):
+        ops.set_reserved_cus(-1)
+
+
 def test_overlapped_step_equals_serial_step_one_rank_rccl():
     """The step with its single all-reduce + Adam on a side stream, overlapped with the next batch's frozen backbone
     (wait=False), gives the same bits as the serial step, over 3 steps, through RCCL (backend nccl) on one rank; and the

@@ -60,6 +60,32 @@ def test_static_scratch_entry_point_matches_workspace_entry_point():
     assert torch.equal(a, b)
 
 
+def test_static_scratch_entry_point_under_graph_capture():
+    """The callers this entry point is for: after ty1_static_scratch_init() and one eager call (which loads the kernel and
+    runs the one-time occupancy query of its tile configuration), the call is captured in a HIP graph and replayed on new
+    input; the replays give the eager call's bits."""
+    ops.static_scratch_init()
+    N, H, cin, cout, pool = 12, 7, 1024, 256, False
+    x, w, scale, shift = _problem(N, H, cin, cout, seed=5)
+    assert ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool) > 0
+    out = torch.empty((N, H, H, cout), dtype=torch.float32, device=DEV)
+    eager = ops.conv3x3_bn_leaky_static(x, w, scale, shift, pool, 0.1, out).clone()
+    torch.cuda.synchronize()
+    out.fill_(float('nan'))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.conv3x3_bn_leaky_static(x, w, scale, shift, pool, 0.1, out)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    x2, _, _, _ = _problem(N, H, cin, cout, seed=6)
+    want2 = ops.conv3x3_bn_leaky_static(x2, w, scale, shift, pool, 0.1, torch.empty_like(out))
+    x.copy_(x2)                      # the graph reads the buffers it was captured with
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want2)
+
+
 def test_static_scratch_entry_point_rejects_what_does_not_fit():
     # the network's last layer at batch 128 wants 20 MB of partial tiles (every layer at batch 64 fits)
     assert ops.conv3x3_workspace_bytes(128, 7, 7, 1024, 256, False) > ops.static_scratch_bytes()

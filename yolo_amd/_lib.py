@@ -18,6 +18,7 @@ SIGNATURES = {
     'ty1_conv3x3_bn_leaky_ws_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _c.c_size_t, _vp],
     'ty1_conv3x3_bn_leaky_static_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     'ty1_static_scratch_bytes': [],
+    'ty1_static_scratch_init': [],
     'ty1_conv3x3_workspace_bytes_bf16': [_i, _i, _i, _i, _i, _i, _vp],
     'ty1_conv3x3_bn_leaky_bf16': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _c.c_size_t, _vp],
     'ty1_cast_f32_to_bf16': [_vp, _vp, _i64, _vp],
@@ -37,6 +38,8 @@ SIGNATURES = {
     'ty1_train_tail_f32': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     'ty1_dense_wgrad_f32': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'ty1_adam_step_f32': [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i64, _vp],
+    'ty1_set_reserved_cus': [_i],
+    'ty1_get_reserved_cus': [_c.POINTER(_i)],
     'ty1_prof_enable': [_i],
     'ty1_prof_reset': [],
     'ty1_prof_filter': [_c.c_char_p],

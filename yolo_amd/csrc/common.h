@@ -40,6 +40,14 @@ inline const char *dev_env(const char *name) { return getenv(name); }
 inline const char *dev_env(const char *) { return nullptr; }
 #endif
 
+// CU count of the CURRENT device, cached per device id (one process may drive several GPUs; safe from several host
+// threads).  Plans (tile choice, K-split pieces, Dense splits) are made for this count.
+int num_cus();
+// CUs a persistent grid may fill: num_cus() minus the count set with ty1_set_reserved_cus (at least 8).  Only the
+// NUMBER OF WORKGROUPS of a launch follows it; the work items and their order of summation do not, so results are
+// bit-identical for every setting.
+int grid_cus();
+
 // developer timeline buffer (8 x i64 per workgroup), set by ty1_debug_stamp_buffer; see tools/stamp_trace.py
 extern long long *g_stamp;
 extern long long g_stamp_cap;

@@ -1,6 +1,7 @@
 // libty1.so: error state, BN folding (host), per-kernel event profiling.
 #include "common.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -24,6 +25,23 @@ int fail(const char *fmt, ...) {
     va_end(ap);
     last_error() = buf;
     return 1;
+}
+
+int num_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess) return cus;
+    if (dev >= 0 && dev < 64 && cache[dev].load(std::memory_order_relaxed) > 0) return cache[dev].load(std::memory_order_relaxed);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
+static std::atomic<int> g_reserved_cus{0};
+
+int grid_cus() {
+    const int n = num_cus() - g_reserved_cus.load(std::memory_order_relaxed);
+    return n < 8 ? (num_cus() < 8 ? num_cus() : 8) : n;
 }
 
 struct ProfEntry {
@@ -102,6 +120,18 @@ int ty1_fold_bn(const float *gamma, const float *beta, const float *mean, const 
         scale[c] = s;
         shift[c] = beta[c] - mean[c] * s;
     }
+    return 0;
+}
+
+int ty1_set_reserved_cus(int k) {
+    TY1_REQUIRE(k >= 0, "ty1_set_reserved_cus: k=%d must be >= 0", k);
+    ty1::g_reserved_cus.store(k, std::memory_order_relaxed);
+    return 0;
+}
+
+int ty1_get_reserved_cus(int *k) {
+    TY1_REQUIRE(k, "ty1_get_reserved_cus: null result pointer");
+    *k = ty1::g_reserved_cus.load(std::memory_order_relaxed);
     return 0;
 }
 

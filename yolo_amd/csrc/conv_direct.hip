@@ -777,12 +777,6 @@ __global__ __launch_bounds__(256) void conv3x3_c3p_kernel(const float *__restric
 namespace ty1 {
 
 namespace {
-int cu_count() {
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-        cus = 256;
-    return cus;
-}
 // workgroups of `kernel` (256 threads, static LDS) that one CU keeps resident, at most `cap`; `env` is a developer override
 template <typename K>
 int resident_blocks(K kernel, int cap, const char *env) {
@@ -809,7 +803,7 @@ int conv3x3_c16_direct(const float *x, const float *w, const float *scale, const
 #define TY1_C16(PL, NTV)                                                                                              \
     do {                                                                                                              \
         static const int per_cu = resident_blocks(conv3x3_c16_kernel<PL, NTV>, 2, "TY1_C16_BLOCKS");                  \
-        const long long want = (long long)per_cu * cu_count();                                                        \
+        const long long want = (long long)per_cu * ty1::grid_cus();                                                        \
         conv3x3_c16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(          \
             x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, make_fastdiv_u((unsigned)tiles_x),      \
             make_fastdiv_u((unsigned)tiles_y));                                                                       \
@@ -839,7 +833,7 @@ int conv3x3_c16_direct_bf16(const void *x, const void *w, const float *scale, co
 #define TY1_C16B(PL, NTV)                                                                                             \
     do {                                                                                                              \
         static const int per_cu = resident_blocks(conv3x3_c16_bf16_kernel<PL, NTV>, 4, "TY1_C16B_BLOCKS");            \
-        const long long want = (long long)per_cu * cu_count();                                                        \
+        const long long want = (long long)per_cu * ty1::grid_cus();                                                        \
         conv3x3_c16_bf16_kernel<PL, NTV><<<dim3((unsigned)(patches < want ? patches : want)), dim3(256), 0, s>>>(     \
             xb, wb, scale, shift, yb, N, H, W, Cout, alpha, tiles_x, tiles_y, P, make_fastdiv_u((unsigned)tiles_x),  \
             make_fastdiv_u((unsigned)tiles_y));                                                                       \
@@ -868,7 +862,7 @@ int conv3x3_c3_persistent(const float *x, const float *w, const float *scale, co
 #define TY1_C3P(PL, NTV, OB)                                                                                          \
     do {                                                                                                              \
         static const int per_cu = resident_blocks(conv3x3_c3p_kernel<PL, NTV, OB>, 4, "TY1_C3_BLOCKS");               \
-        const long long want = (long long)per_cu * cu_count();                                                        \
+        const long long want = (long long)per_cu * ty1::grid_cus();                                                        \
         const long long nblk = patches < want ? patches : want;                                                       \
         conv3x3_c3p_kernel<PL, NTV, OB><<<dim3((unsigned)nblk), dim3(256), 0, s>>>(                                   \
             x, w, scale, shift, y, N, H, W, Cout, alpha, tiles_x, tiles_y, P, nblk <= g_stamp_cap ? g_stamp : nullptr, dbg, \

@@ -865,17 +865,7 @@ void launch_c3(int nt, dim3 grid, hipStream_t s, const float *x, const float *w,
     }
 }
 
-// CU count of the CURRENT device, cached per device id (one process may drive several GPUs).
-int num_cus() {
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cus[dev];
-}
+using ty1::num_cus;
 
 // How to run T equal tiles of C chunks each on `slots` CUs (see the header comment).  Costs are in chunk-times
 // of one CU: a tile costs C, every block pays a fixed `ovh` (prologue, first fetch, epilogue), the two extra
@@ -947,7 +937,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
         if (cap && atoi(cap) > 0 && n > atoi(cap)) n = atoi(cap);
         return n > 4 ? 4 : n;
     }();
-    const int grid = items < occ * num_cus() ? items : occ * num_cus();
+    const int grid = items < occ * ty1::grid_cus() ? items : occ * ty1::grid_cus();
     a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
     static const char *dbg = ty1::dev_env("TY1_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
@@ -1228,6 +1218,11 @@ int static_scratch_ptr(void **out) {
 }  // namespace
 
 extern "C" size_t ty1_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int ty1_static_scratch_init(void) {
+    void *ptr = nullptr;
+    return static_scratch_ptr(&ptr);
+}
 
 extern "C" int ty1_conv3x3_bn_leaky_static_f32(const float *x, const float *w, const float *scale, const float *shift,
                                                float *y, int N, int H, int W, int Cin, int Cout, int pool, float alpha,

@@ -495,16 +495,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RES_B ? 2 : 1) void conv_ha
     }
 }
 
-int num_cus_here() {       // cached per device id (one process may drive several GPUs)
-    static std::atomic<int> cache[64];
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess) return cus;
-    if (dev >= 0 && dev < 64 && cache[dev].load(std::memory_order_relaxed) > 0) return cache[dev].load(std::memory_order_relaxed);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
-    return cus;
-}
-
 // y = LeakyReLU(scale * sum over the K slices + shift) for the partial tiles of a K-split launch (NI images of P pixels per
 // tile, rows in image order); slices are added in index order.  One thread per four channels of a row.
 template <int TROWS, int BN>
@@ -539,7 +529,7 @@ int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     const long long items = (long long)((a.NB + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.ntiles * (KSPL ? a.splits : 1);
     TY1_REQUIRE(items < (1ll << 31), "ty1_conv3x3_bf16(halo): too many work items");
     a.items = (int)items;
-    const long long want = (long long)per_cu * num_cus_here();
+    const long long want = (long long)per_cu * ty1::grid_cus();
     const double px = (double)a.NB * a.H * a.W;
     {
         ty1::ProfScope prof(name, s, 2.0 * px * a.Cout * 9 * a.Cin, 2.0 * (px * a.Cin + 9.0 * a.Cin * a.Cout + px * a.Cout / (NI == 1 ? 4 : 1)));
@@ -559,42 +549,59 @@ int launch_halo(const char *name, HaloArgs a, int per_cu, hipStream_t s) {
     return 0;
 }
 
-}  // namespace
+// Which halo instantiation runs a bf16 layer, decided in ONE place: the support query, the workspace query and the
+// launcher all switch on this plan (never on H / W / Cin again), so a layer can only reach the instantiation whose K depth
+// and patch shape the acceptance rule - and the tests - mean.
+enum HaloKind { HALO_NONE = 0, HALO_C32, HALO_8X28, HALO_14X14, HALO_4X7X7, HALO_4X7X7_KSPLIT };
+struct HaloPlan {
+    HaloKind kind;
+    int slices;          // K slices of HALO_4X7X7_KSPLIT, else 1
+};
 
-namespace ty1 {
-
-// 1 if a halo instantiation exists for this pooled bf16 layer and it has enough work items to balance the chip
-// (then conv3x3_halo_bf16 runs it), 0 otherwise: the caller falls back to the implicit-GEMM kernel.
-int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool) {
-    if ((long long)4 * H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return 0;
-    const long long cus = num_cus_here();
+HaloPlan halo_plan(int N, int H, int W, int Cin, int Cout, int pool) {
+    const HaloPlan none{HALO_NONE, 1};
+    if ((long long)4 * H * W * Cin * 2 + (long long)(W + 1) * Cin * 2 >= (1ll << 31)) return none;
+    const long long cus = ty1::num_cus();
     const bool force = ty1::dev_env("TY1_HALO_FORCE") != nullptr;     // developer sweep: every shape the kernels can run
     if (!pool) {
         // 7x7 maps without a pool, four whole images per item: one item is Cin / 64 x 9 weight stages long, so only when
         // the items come in whole rounds of the chip (7x7x512->1024 at 128 images: 256 items)
         if (H == 7 && W == 7 && Cin % 64 == 0 && Cout % 128 == 0 && !ty1::dev_env("TY1_NO_HALO7")) {
             const long long items = (long long)((N + 3) / 4) * (Cout / 128);
-            if (items >= cus) return Cin <= 512 && (force || items % cus == 0);
+            if (items >= cus) return (Cin <= 512 && (force || items % cus == 0)) ? HaloPlan{HALO_4X7X7, 1} : none;
             // too few tiles for the chip (7x7x1024->256 at 128 images: 64, 7x7x512->1024 at 64 images: 128): the items are K
             // slices whose raw accumulators go to a workspace (conv3x3_halo_bf16_ws_bytes), a second launch sums them
             if (Cin >= 512 && Cin <= 2048 && !ty1::dev_env("TY1_NO_HALO7K"))
                 for (int sp = 2; sp <= 8; sp *= 2)
-                    if ((Cin / 64) % sp == 0 && Cin / 64 / sp >= 2 && ((items * sp) % cus == 0 || (force && items * sp >= cus))) return sp;
+                    if ((Cin / 64) % sp == 0 && Cin / 64 / sp >= 2 && ((items * sp) % cus == 0 || (force && items * sp >= cus)))
+                        return HaloPlan{HALO_4X7X7_KSPLIT, sp};
         }
-        return 0;
+        return none;
     }
     // item-count thresholds: tools/experiments/halo_batch_sweep.sh (16 ... 256 images, every shape forced vs the implicit GEMM)
-    if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0) return force || (long long)N * (H / 16) * (W / 16) >= 3 * cus;
+    if (Cin == 32 && Cout == 64 && H % 16 == 0 && W % 16 == 0)
+        return (force || (long long)N * (H / 16) * (W / 16) >= 3 * cus) ? HaloPlan{HALO_C32, 1} : none;
     if ((Cin == 64 || Cin == 128) && Cout % 128 == 0 && H % 8 == 0 && W % 28 == 0)      // one or two K chunks: what the tests cover
-        return force || (long long)N * (H / 8) * (W / 28) * (Cout / 128) * 4 >= 3 * cus;
+        return (force || (long long)N * (H / 8) * (W / 28) * (Cout / 128) * 4 >= 3 * cus) ? HaloPlan{HALO_8X28, 1} : none;
     // 28x28 / 14x14 maps: 14x14 patches (196 pixels of a 256-row tile: a quarter of the rows is padding, and the kernel is
     // still 5-27 % faster than the im2col loop) - but an item is 18-36 weight stages long, so only when the items come
     // in whole rounds of the chip (one round is enough) or there are many of them
     if ((Cin == 128 || Cin == 256) && Cout % 128 == 0 && H % 14 == 0 && W % 14 == 0 && !ty1::dev_env("TY1_NO_HALO14")) {
         const long long items = (long long)N * (H / 14) * (W / 14) * (Cout / 128);
-        return force || (items >= cus && (items % cus == 0 || items >= 8 * cus));
+        return (force || (items >= cus && (items % cus == 0 || items >= 8 * cus))) ? HaloPlan{HALO_14X14, 1} : none;
     }
-    return 0;
+    return none;
+}
+
+}  // namespace
+
+namespace ty1 {
+
+// 0: no halo instantiation takes this bf16 layer (the caller runs the implicit-GEMM kernel); 1: one does; >= 2: one does,
+// with that many K slices (and a workspace, conv3x3_halo_bf16_ws_bytes).
+int conv3x3_halo_bf16_supported(int N, int H, int W, int Cin, int Cout, int pool) {
+    const HaloPlan p = halo_plan(N, H, W, Cin, Cout, pool);
+    return p.kind == HALO_NONE ? 0 : (p.kind == HALO_4X7X7_KSPLIT ? p.slices : 1);
 }
 
 // workspace bytes of a layer conv3x3_halo_bf16_supported() accepts (0: none needed)
@@ -616,25 +623,29 @@ int conv3x3_halo_bf16(const void *x, const void *w, const float *scale, const fl
 #ifdef TY1_DEV_STAMPS
     a.stamp = ty1::g_stamp;
 #endif
-    const int slices = pool ? 1 : conv3x3_halo_bf16_supported(N, H, W, Cin, Cout, pool);
+    const HaloPlan plan = halo_plan(N, H, W, Cin, Cout, pool);
+    TY1_REQUIRE(plan.kind != HALO_NONE, "ty1_conv3x3_bf16(halo): no halo instantiation for N=%d %dx%d %d->%d pool=%d", N, H, W, Cin, Cout, pool);
     // every wave owns 64 x 64 of the tile as 4 x 4 blocks of v_mfma_f32_16x16x32_bf16 (in-call A/Bs against 2 x 2 blocks of
     // 32x32x16: -1.5 ... -3 % per layer timed alone; whole bf16 network +5.4, +4.4, +0.4 and -1.5 % images/s on four devices)
-    if (ty1::dev_env("TY1_HALO_M32") && slices < 2) {          // developer override: 2 x 2 blocks of 32x32x16
-        if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
-        if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
-        if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
-        return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+    if (ty1::dev_env("TY1_HALO_M32") && plan.kind != HALO_4X7X7_KSPLIT) {          // developer override: 2 x 2 blocks of 32x32x16
+        switch (plan.kind) {
+            case HALO_4X7X7: return launch_halo<64, 128, 4, 2, 7, 7, false, 4>("conv_halo_bf16_4x7x7", a, 1, s);
+            case HALO_C32: return launch_halo<32, 64, 4, 1, 16, 16, true>("conv_halo_bf16_c32", a, 2, s);
+            case HALO_14X14: return launch_halo<64, 128, 4, 2, 14, 14, false>("conv_halo_bf16_14x14", a, 1, s);
+            default: return launch_halo<64, 128, 4, 2, 8, 28, false>("conv_halo_bf16_8x28", a, 1, s);
+        }
     }
-    if (slices >= 2) {
-        a.splits = slices;
-        a.part = ws;
-        TY1_REQUIRE(ws, "ty1_conv3x3_bf16(halo): K-sliced layer without workspace");
-        return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>("conv_halo_bf16_4x7x7_ksplit", a, 1, s);
+    switch (plan.kind) {
+        case HALO_4X7X7_KSPLIT:
+            a.splits = plan.slices;
+            a.part = ws;
+            TY1_REQUIRE(ws, "ty1_conv3x3_bf16(halo): K-sliced layer without workspace");
+            return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true, 8, true>("conv_halo_bf16_4x7x7_ksplit", a, 1, s);
+        case HALO_4X7X7: return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>("conv_halo_bf16_4x7x7", a, 1, s);
+        case HALO_C32: return launch_halo<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true>("conv_halo_bf16_c32", a, 2, s);
+        case HALO_14X14: return launch_halo<64, 128, 4, 2, 14, 14, false, 1, 4, 4, true>("conv_halo_bf16_14x14", a, 1, s);
+        default: return launch_halo<64, 128, 4, 2, 8, 28, false, 1, 4, 4, true>("conv_halo_bf16_8x28", a, 1, s);
     }
-    if (!pool) return launch_halo<64, 128, 4, 2, 7, 7, false, 4, 4, 4, true>("conv_halo_bf16_4x7x7", a, 1, s);
-    if (Cin == 32) return launch_halo<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true>("conv_halo_bf16_c32", a, 2, s);
-    if (W % 28 != 0 || H % 8 != 0) return launch_halo<64, 128, 4, 2, 14, 14, false, 1, 4, 4, true>("conv_halo_bf16_14x14", a, 1, s);
-    return launch_halo<64, 128, 4, 2, 8, 28, false, 1, 4, 4, true>("conv_halo_bf16_8x28", a, 1, s);
 }
 
 }  // namespace ty1

@@ -91,7 +91,9 @@ class DeviceModel:
         return ops.head_activate(part, self.dense_b, self.S, self.B, self.C, out=ws['y'])
 
     def predict(self, x):
-        """-> y_pred (N,S,S,C+5B) on the device (valid until the next call with the same N)."""
+        """-> y_pred (N,S,S,C+5B) on the device (valid until the next call with the same N).
+        With a Trainer attached: an update left in flight by step(wait=False) must be joined first (Trainer.join()),
+        otherwise this forward reads the weights from before it.  The same holds for detect()."""
         ws = self.workspace(x.shape[0])
         return self.head(self.backbone(x, ws), ws)
 
@@ -202,6 +204,10 @@ class Trainer:
         # MFMA-bound layers behind them it is nearly free.  The all-reduce itself always starts at once.
         self.update_after_layer = Trainer.UPDATE_AFTER_LAYER
         self._adam_deferred = False
+        # CUs the NEXT batch's persistent conv grids leave free while this step's exchange is in flight (ty1_set_reserved_cus):
+        # somewhere for RCCL's workgroups to run.  0 = fill the chip (the default until an 8-GPU run says otherwise);
+        # results do not depend on it.
+        self.reserve_cus = 0
 
     def gradients(self, x, y_true):
         """Forward + backward on this rank's shard: fills self.dwt / self.db, returns the local loss (1,)."""
@@ -209,7 +215,10 @@ class Trainer:
 
     def gradients_from_features(self, feats, y_true):
         """The trainable part of the step (Dense -> head -> yolo_loss and back) on frozen-backbone features (N, K).
-        Writes dWt, db and the local loss into the bucket; returns the bucket's loss slot."""
+        Writes dWt, db and the local loss straight into the all-reduce bucket and returns the bucket's loss slot: a VIEW
+        that the next call (or the next collective) overwrites - clone it to keep it.  An update still in flight on the
+        side stream (step(wait=False)) is joined first: it reads the bucket this call writes."""
+        self.join()
         m = self.model
         N = feats.shape[0]
         ws = m.workspace(N)
@@ -260,7 +269,9 @@ class Trainer:
                 e0.record()
             work = self.bucket.allreduce(self.group, async_op=True)
             if work is not None:
-                work.wait()                      # stream-ordered wait on the collective's stream, not a host wait
+                # nccl (RCCL): makes the current stream wait for the collective's stream, the host goes on (that is what the
+                # overlap is built on).  gloo (CPU tests, rehearsals): blocks the HOST until the exchange is done.
+                work.wait()
             if self.time_collective:
                 e1.record()
                 self.collective_events = (e0, e1)
@@ -276,7 +287,14 @@ class Trainer:
         wait=False leaves the exchange + update in flight on the side stream (the next step() or join() waits for it
         in front of its Dense forward); the returned loss is then valid only after join() / a device synchronise."""
         hook = (self.update_after_layer, self._launch_deferred_adam) if self._adam_deferred else None
-        feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the update in flight
+        shrink = self.reserve_cus > 0 and self._pending
+        if shrink:
+            ops.set_reserved_cus(self.reserve_cus)
+        try:
+            feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the update in flight
+        finally:
+            if shrink:
+                ops.set_reserved_cus(0)
         self.join()
         self.gradients_from_features(feats, y_true)
         if self.side is None:

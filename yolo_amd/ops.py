@@ -78,6 +78,23 @@ def static_scratch_bytes():
     return int(_lib.lib().ty1_static_scratch_bytes())
 
 
+def static_scratch_init():
+    """Resolve the static scratch array's address on the current device (once per device, outside graph capture)."""
+    _lib.call('ty1_static_scratch_init')
+
+
+def set_reserved_cus(k):
+    """Persistent grids leave k CUs free from now on (0: fill the chip).  Results do not depend on k."""
+    _lib.call('ty1_set_reserved_cus', int(k))
+
+
+def get_reserved_cus():
+    import ctypes
+    k = ctypes.c_int(0)
+    _lib.call('ty1_get_reserved_cus', ctypes.byref(k))
+    return int(k.value)
+
+
 def conv3x3_bn_leaky_static(x, w_ohwi, scale, shift, pool, alpha, out):
     """The conv block through the entry point that allocates nothing (ty1_conv3x3_bn_leaky_static_f32): the caller
     brings every buffer, the K-split scratch is the library's static device array."""
