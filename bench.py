@@ -37,7 +37,7 @@ GFLOP_PER_IMAGE = 3.216          # 2 x 1,608,015,360 MACs
 # libty1 event-timer family -> kernel symbol as rocprofv3 --kernel-trace prints it (profiles/pmc_traffic*.json keys)
 _CFG = {'128x128': '2, 2, 2, 2, 32', '128x64': '2, 1, 2, 2, 32', '64x64': '1, 1, 2, 2, 32', '256x32': '2, 1, 4, 1, 32',
         'bk16_128x64': '2, 1, 2, 2, 16', 'bk16_256x32': '2, 1, 4, 1, 16', '256x128': '2, 2, 4, 2, 32', '256x64': '2, 1, 4, 2, 32'}
-ROCPROF_SYMBOL = {'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv3x3_c16_pool': 'conv3x3_c16_kernel<true, 1>',
+ROCPROF_SYMBOL = {'conv01_fused_bf16': 'conv01_fused_bf16_kernel', 'conv3x3_c3_pool': 'conv3x3_c3p_kernel<true, 1, false>', 'conv3x3_c16_pool': 'conv3x3_c16_kernel<true, 1>',
                   'conv3x3_c3_pool_bf16out': 'conv3x3_c3p_kernel<true, 1, true>',
                   'conv3x3_c16_bf16_pool': 'conv3x3_c16_bf16_kernel<true, 1>',
                   'conv_halo_bf16_c32': 'conv_halo_bf16_kernel<32, 64, 4, 1, 16, 16, true, 1, 4, 4, true, 4, false>',
@@ -286,6 +286,7 @@ def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
     detailed = detailed and not args.graph      # a replayed graph has no per-launch brackets: no kernel table / roofline
     prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')   # SURVEY 8d stress distribution
     model = DeviceModel(prm, C=C, device=ctx.dev, dtype=dtype)
+    model.fused01 = not args.no_fused01
     if images_on_device:       # 4096 images are 9.9 GB: drawn on the device (torch's Philox generator), no host copy
         x_cpu = None
         x = torch.rand((N, 448, 448, 3), device=ctx.dev, generator=torch.Generator(device=ctx.dev).manual_seed(0))
@@ -497,6 +498,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the CPU-baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the configs[2] / configs[3] measurements under "also"')
+    ap.add_argument('--no-fused01', action='store_true', help='bf16 inference: conv blocks 0 and 1 as two launches instead of one (A/B)')
     ap.add_argument('--graph', action='store_true', help='inference: replay the step as one HIP graph (DeviceModel.detect_replay)')
     ap.add_argument('--update-after-layer', type=int, default=None,
                     help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')

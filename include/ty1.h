@@ -264,6 +264,19 @@ int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, int64_t n, f
                       float beta2, float eps, int64_t t, ty1_stream_t stream);
 
 /*
+ * The first two blocks of the bf16 network in one launch - convolution_0 and convolution_1 with their BatchNormalization,
+ * LeakyReLU and MaxPooling2D layers (/root/reference/models/model_tiny_yolov1.py:43-53) - so that the (H/2, W/2, 16) tensor
+ * between them stays in LDS instead of crossing HBM twice:
+ *   y = pool(leaky(bn1(conv3x3(pool(leaky(bn0(conv3x3(x, w0)))), w1))))
+ * x (N,H,W,3) fp32 NHWC and w0 (16,3,3,3) fp32 OHWI are rounded to bf16 inside the kernel, w1 (32,3,3,16) is bf16 OHWI,
+ * y (N,H/4,W/4,32) is bf16; accumulation, BN, LeakyReLU and pool are fp32, the intermediate tensor is rounded to bf16 -
+ * the rounding points of ty1_conv3x3_bn_leaky_bf16 called twice.  H, W multiples of 4; 0 < alpha <= 1.
+ */
+int ty1_conv3x3_x2_c3_bf16(const float *x, const float *w0, const float *scale0, const float *shift0, const void *w1,
+                           const float *scale1, const float *shift1, void *y, int N, int H, int W, float alpha,
+                           ty1_stream_t stream);
+
+/*
  * Room for a collective next to the persistent kernels.  No counterpart in the reference (it has no second device).
  * Every persistent launch of the library (conv blocks in fp32 and bf16) sizes its grid to the workgroups that stay
  * resident on (CU count - k) compute units; k = 0 (the default) fills the chip.  engine.Trainer can set k > 0 while its

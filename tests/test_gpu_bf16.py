@@ -134,6 +134,100 @@ def test_conv_block_bf16_halo_k_slices_vs_oracle(N, cin, cout, slices):
         assert (got == bf16_round(ref)).mean() > 0.99
 
 
+# ------------------------------------------------------------------------------- first two blocks in one launch
+def _fused_case(N, H, W, seed, neg_scale=True):
+    """-> (got f32 array, oracle, two-launch result, operands): ty1_conv3x3_x2_c3_bf16 against the oracle's two conv blocks with the
+    bf16 network's rounding points (image, weights and the tensor between the blocks rounded to bf16)."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((N, H, W, 3)).astype(np.float32)
+    blocks = []
+    for cin, cout in ((3, 16), (16, 32)):
+        w = P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)
+        gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        if neg_scale:
+            gamma[::3] *= -1                     # the kernel folds sign(scale) into its weights: exercise both signs
+        beta, mean = rng.uniform(-0.5, 0.5, cout).astype(np.float32), rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+        var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        blocks.append((w, gamma, beta, mean, var))
+    t = torch.from_numpy(bf16_round(x)).permute(0, 3, 1, 2).contiguous()
+    for w, gamma, beta, mean, var in blocks:
+        t = torch.from_numpy(bf16_round(model_ref.conv_block_ref(t, bf16_round(w), gamma, beta, mean, var, True).numpy()))
+    ref = t.permute(0, 2, 3, 1).contiguous().numpy()
+    (w0, *bn0), (w1, *bn1) = blocks
+    sc0, sh0 = ops.fold_bn(*bn0)
+    sc1, sh1 = ops.fold_bn(*bn1)
+    ops_ = dict(x=dev(x), w0=dev(P.hwio_to_ohwi(w0)), sc0=dev(sc0), sh0=dev(sh0), w1=dev(P.hwio_to_ohwi(w1), torch.bfloat16),
+                sc1=dev(sc1), sh1=dev(sh1))
+    oshape = (N, H // 4, W // 4, 32)
+    numel, guard = int(np.prod(oshape)), 1 << 18
+    buf = torch.full((numel + 2 * guard,), 77.0, dtype=torch.bfloat16, device=DEV)
+    out = buf[guard:guard + numel].view(oshape)
+    got = ops.conv3x3_x2_c3_bf16(ops_['x'], ops_['w0'], ops_['sc0'], ops_['sh0'], ops_['w1'], ops_['sc1'], ops_['sh1'], out=out)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 77.0).all()) and bool((buf[guard + numel:] == 77.0).all()), 'write outside the output tensor'
+    mid = ops.conv3x3_bn_leaky_bf16(ops_['x'], ops_['w0'], ops_['sc0'], ops_['sh0'], True)
+    two = ops.conv3x3_bn_leaky_bf16(mid, ops_['w1'], ops_['sc1'], ops_['sh1'], True)
+    return got.float().cpu().numpy(), ref, two.float().cpu().numpy(), ops_
+
+
+def _check_fused(got, ref, two):
+    # block-1 outputs inherit the rounding flips of block 0 (an fp32 sum in another order moves a few block-0 values to the
+    # neighbouring bf16), so the bar is the bf16 bar of one layer with a doubled absolute term; the share of outputs that
+    # are exactly the oracle's bf16 stays above 97 % [measured 98.5-99.5 %].  Against the two separate launches: the same bar.
+    for want in (ref, two):
+        err = np.abs(got - want)
+        assert (err <= 2.0 ** -7 * np.abs(want) + 4e-3).all(), float(err.max())
+        assert (got == want).mean() > 0.97, float((got == want).mean())
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 448, 448), (1, 64, 128), (1, 40, 72), (3, 100, 52), (2, 4, 4), (1, 68, 132), (5, 32, 64)])
+def test_fused_first_two_blocks_vs_oracle(N, H, W):
+    """Whole patches (448 x 448 = 14 x 7 of them per image), one patch exactly (64 x 128), ragged last patches in both
+    directions (40 x 72: 20 x 36 block-1 pixels on 16 x 32 patches; 100 x 52; 68 x 132: one row / column of patches that
+    holds four pixels), and an image smaller than a patch."""
+    got, ref, two, _ = _fused_case(N, H, W, seed=H + W)
+    assert got.shape == ref.shape == (N, H // 4, W // 4, 32)
+    _check_fused(got, ref, two)
+
+
+def test_fused_first_two_blocks_full_batch_properties():
+    """configs[2]'s batch (128 images per GPU): determinism, the first / a middle / the last image against the oracle,
+    every image against the two separate launches."""
+    N = 128
+    prm = P.make_random_params(seed=3, dense_init='glorot', bn='random')
+    x = torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(2))
+    xd = x.to(DEV)
+    sc0, sh0 = ops.fold_bn(prm['bn0_gamma'], prm['bn0_beta'], prm['bn0_mean'], prm['bn0_var'])
+    sc1, sh1 = ops.fold_bn(prm['bn1_gamma'], prm['bn1_beta'], prm['bn1_mean'], prm['bn1_var'])
+    w0, w1 = dev(P.hwio_to_ohwi(prm['conv0_w'])), dev(P.hwio_to_ohwi(prm['conv1_w']), torch.bfloat16)
+    args = (xd, w0, dev(sc0), dev(sh0), w1, dev(sc1), dev(sh1))
+    got = ops.conv3x3_x2_c3_bf16(*args)
+    assert torch.equal(ops.conv3x3_x2_c3_bf16(*args), got)
+    two = ops.conv3x3_bn_leaky_bf16(ops.conv3x3_bn_leaky_bf16(xd, w0, args[2], args[3], True), w1, args[5], args[6], True)
+    pick = [0, 77, 127]
+    t = torch.from_numpy(bf16_round(x[pick].numpy())).permute(0, 3, 1, 2).contiguous()
+    for i in range(2):
+        t = torch.from_numpy(bf16_round(model_ref.conv_block_ref(t, bf16_round(prm[f'conv{i}_w']), prm[f'bn{i}_gamma'], prm[f'bn{i}_beta'],
+                                                                 prm[f'bn{i}_mean'], prm[f'bn{i}_var'], True).numpy()))
+    ref = t.permute(0, 2, 3, 1).contiguous().numpy()
+    g = got.float().cpu().numpy()
+    _check_fused(g[pick], ref, two.float().cpu().numpy()[pick])
+    err = (got.float() - two.float()).abs()
+    assert bool((err <= 2.0 ** -7 * two.float().abs() + 4e-3).all())
+
+
+def test_fused_first_two_blocks_rejects_what_it_does_not_cover():
+    x = torch.zeros((1, 6, 8, 3), device=DEV)
+    w0, w1 = torch.zeros((16, 3, 3, 3), device=DEV), torch.zeros((32, 3, 3, 16), dtype=torch.bfloat16, device=DEV)
+    s16, s32 = torch.ones(16, device=DEV), torch.ones(32, device=DEV)
+    with pytest.raises(Exception, match='multiples of 4'):
+        ops.conv3x3_x2_c3_bf16(x, w0, s16, s16, w1, s32, s32)
+    x = torch.zeros((1, 8, 8, 3), device=DEV)
+    with pytest.raises(Exception, match='alpha'):
+        ops.conv3x3_x2_c3_bf16(x, w0, s16, s16, w1, s32, s32, alpha=0.0)
+    assert ops.conv3x3_x2_c3_bf16(torch.zeros((0, 8, 8, 3), device=DEV), w0, s16, s16, w1, s32, s32).shape == (0, 2, 2, 32)
+
+
 @pytest.mark.parametrize('N', [1, 33, 64, 70, 128, 130])
 def test_dense_splitk_bf16_vs_oracle(N):
     """ty1_dense_splitk_bf16 at the batch sizes of its tile shapes (32 x 128 up to 32 rows, 64 x 64 above; ragged last row
@@ -191,6 +285,8 @@ def test_model_bf16_end_to_end(dense_init):
     z = ws['part'].sum(0)[:, :model.units].cpu().numpy() + prm['dense_b']
     feats_a, acts_a = model_ref.backbone_ref(x, prm, return_all=True, bf16=True)
     for i, (a_got, a_ref) in enumerate(zip(ws['acts'], acts_a)):
+        if i == 0 and model.fused01:
+            continue                      # blocks 0 and 1 run as one launch: the tensor between them never reaches HBM
         g = a_got.float().cpu().numpy()
         err = np.abs(g - a_ref).max() / max(1.0, np.abs(a_ref).max())
         print(f'layer {i}: max err / max |ref| = {err:.2e}')

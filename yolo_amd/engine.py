@@ -41,6 +41,7 @@ class DeviceModel:
         self.dense_wt_bf16 = ops.cast_bf16(self.dense_wt) if dtype == 'bf16' else None
         self._ws = {}
         self._graphs, self._inputs = {}, {}
+        self.fused01 = True      # bf16: conv blocks 0 and 1 in one launch (ty1_conv3x3_x2_c3_bf16); False: two launches (A/B, tests)
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, N):
@@ -73,9 +74,16 @@ class DeviceModel:
         after_layer: optional (index, callable) - the callable runs on the host once layer `index` has been enqueued
         (the trainer uses it to start the deferred Adam launch under the compute-bound layers)."""
         ws = ws or self.workspace(x.shape[0])
+        fused01 = self.fused01 and self._fusable01(x)
         for i, (layer, out) in enumerate(zip(self.conv, ws['acts'])):
             if after_layer is not None and i == after_layer[0] + 1:
                 after_layer[1]()
+            if fused01 and i < 2:          # blocks 0 and 1 of the bf16 network are one launch: the tensor between them stays in LDS
+                if i == 1:
+                    l0 = self.conv[0]
+                    x = ops.conv3x3_x2_c3_bf16(x, l0['w'], l0['scale'], l0['shift'], layer['w'], layer['scale'], layer['shift'],
+                                               LEAKY_ALPHA, out=out)
+                continue
             if self.dtype == 'bf16':
                 x = ops.conv3x3_bn_leaky_bf16(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA,
                                               out=out, workspace=ws['scratch'])
@@ -83,6 +91,11 @@ class DeviceModel:
                 x = ops.conv3x3_bn_leaky(x, layer['w'], layer['scale'], layer['shift'], layer['pool'], LEAKY_ALPHA, out=out,
                                          workspace=ws['scratch'])
         return x.reshape(x.shape[0], -1)
+
+    def _fusable01(self, x):
+        s = self.specs
+        return (self.dtype == 'bf16' and len(s) >= 2 and tuple(s[0]) == (3, 16, True) and tuple(s[1]) == (16, 32, True)
+                and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0 and 0.0 < LEAKY_ALPHA <= 1.0)
 
     def head(self, feats, ws=None):
         ws = ws or self.workspace(feats.shape[0])

@@ -154,6 +154,27 @@ def conv3x3_bn_leaky_bf16(x, w_ohwi, scale, shift, pool, alpha=0.1, out_f32=Fals
     return out
 
 
+def conv3x3_x2_c3_bf16(x, w0, scale0, shift0, w1, scale1, shift1, alpha=0.1, out=None):
+    """The first two conv blocks of the bf16 network in ONE launch (ty1_conv3x3_x2_c3_bf16): x (N,H,W,3) f32, w0 (16,3,3,3)
+    f32, w1 (32,3,3,16) bf16 -> (N,H/4,W/4,32) bf16; the 16-channel tensor between the blocks stays in LDS."""
+    _chk(x, torch.float32, 'x'); _chk(w0, torch.float32, 'w0'); _chk(w1, torch.bfloat16, 'w1')
+    for name, t in (('scale0', scale0), ('shift0', shift0), ('scale1', scale1), ('shift1', shift1)):
+        _chk(t, torch.float32, name)
+    N, H, W, cin = x.shape
+    if cin != 3 or tuple(w0.shape) != (16, 3, 3, 3) or tuple(w1.shape) != (32, 3, 3, 16):
+        raise ValueError(f'conv3x3_x2_c3_bf16: x {tuple(x.shape)}, w0 {tuple(w0.shape)}, w1 {tuple(w1.shape)} are not the 3 -> 16 -> 32 blocks')
+    if scale0.numel() != 16 or shift0.numel() != 16 or scale1.numel() != 32 or shift1.numel() != 32:
+        raise ValueError('conv3x3_x2_c3_bf16: scale / shift sizes must be 16 and 32')
+    oshape = (N, H // 4, W // 4, 32)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
+    else:
+        _chk_out(out, torch.bfloat16, oshape, 'out')
+    _lib.call('ty1_conv3x3_x2_c3_bf16', x.data_ptr(), w0.data_ptr(), scale0.data_ptr(), shift0.data_ptr(), w1.data_ptr(),
+              scale1.data_ptr(), shift1.data_ptr(), out.data_ptr(), N, H, W, float(alpha), _lib.current_stream())
+    return out
+
+
 def preprocess_u8(img_u8, out_hw=(448, 448), swap_rb=False, out=None):
     """uint8 (H0,W0,3) image on the device -> fp32 (out_h,out_w,3) in [0,1]: cv2.resize INTER_LINEAR + /255
     (utils.py:11-15).  `out` may be one slot x[n] of the network's input batch."""
