@@ -118,7 +118,11 @@ extern "C" int ty1_adam_step_f32(float *p, const float *g, float *m, float *v, i
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
     hipStream_t s = (hipStream_t)stream;
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    // one workgroup per CU: alone the pass then takes 90 us instead of 78 (516 MB), but next to the MFMA-bound conv layers of
+    // the next batch - where the trainer runs it - four waves per CU take fewer issue slots from them than sixteen
+    // (training step at 32 images 1.016 -> 1.000 ms, tools/experiments/adam_grid_ab.sh; 128 per chip is too few: 145 us alone)
+    if (blocks > ty1::num_cus()) blocks = ty1::num_cus();
+    if (const char *e = ty1::dev_env("TY1_ADAM_BLOCKS")) blocks = atoll(e) > 0 && atoll(e) < blocks ? atoll(e) : blocks;     // developer sweep
     if (blocks < 1) blocks = 1;
     ty1::ProfScope prof("adam_step", s);
     adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p, g, m, v, n, (float)lr_t, beta1, beta2, eps);
