@@ -228,7 +228,10 @@ int dense_dispatch(const void *x, const void *wt, float *part, int N, int K, int
         return launch_dense<1, 1, 1, 4, ESZ>(ESZ == 4 ? "dense_f32_32x128" : "dense_bf16_32x128", a, (N + 31) / 32, s);
     }
     a.ntiles = (units + 63) / 64;
-    // (bf16 above 64 rows on 128 x 64 tiles: GEMM + tail 39.3 -> 35.5 us alone, nothing on the whole network: not kept)
+    // (bf16 above 64 rows on 128 x 64 tiles: GEMM + tail 39.3 -> 35.5 us alone, nothing on the whole network: not kept.  Round 3,
+    //  inside the network at 128 images, tools/experiments/dense128_ab.sh: 64x64 21.9 us; one 128x64 tile per column panel - each
+    //  weight byte fetched once - 21.3 us with 11 splits, 19.5 us with 22 but the tail behind it +1.9 us: the re-read traffic is
+    //  not what bounds this kernel, its four MFMAs per wave and barrier are)
     // (four chunks in flight in registers instead of one, bf16: 39.6 vs 39.5 us - the two resident workgroups per CU already
     //  cover the fetch latency: not kept)
     return launch_dense<1, 1, 2, 2, ESZ>(ESZ == 4 ? "dense_f32_64x64" : "dense_bf16_64x64", a, (N + 63) / 64, s);
