@@ -547,9 +547,10 @@ def main():
             legs.append(('configs[4] single-class batch 4096', big, config4))
         for key, leg_args, fn in legs:
             if ctx.multi and ctx.backend != 'nccl' and 'training' in key:
-                # the rehearsal backend stalls in gloo's device-tensor all-reduce of the 74 MB bucket when two ranks share a
-                # card; the two-rank training step itself is covered by tests/test_gpu_ddp.py
-                also[key] = {'skipped': 'rehearsal backend (gloo): training all-reduce not rehearsed here'}
+                # two ranks time-slicing ONE card: the compute stream of one rank stops inside the step's kernels while the
+                # other waits for it in gloo's host all-reduce (profiles/r03_gloo_train_rehearsal_run*.log); the
+                # two-rank training step itself is covered by tests/test_gpu_ddp.py
+                also[key] = {'skipped': 'rehearsal backend (gloo), ranks sharing a card: the training leg stalls on the GPU (DESIGN.md 5)'}
                 continue
             torch.cuda.empty_cache()
             r = fn()
