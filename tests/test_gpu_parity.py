@@ -157,41 +157,6 @@ def test_conv_block_vs_oracle(N, H, cin, cout, pool, use_ws):
     assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_k_split_tail_both_ways_of_summing_it():
-    """The K pieces of a tail tile are summed either by the workgroup that stores the last of them (arrival counters, sc1
-    hand-over inside the conv kernel: layers with >= 128 tiles and <= 512 KB of pieces per tile) or by conv_fixup_kernel in
-    a second launch.  Both legs are pinned here by the launches they make, and the in-kernel hand-over - which rests on
-    measured cache behaviour, not on a fence - is repeated 200 times on a NaN-poisoned workspace: every run must give the
-    first run's bits."""
-    rng = np.random.default_rng(5)
-
-    def launches(N, H, cin, cout, pool, reps):
-        x = dev(rng.random((N, H, H, cin)).astype(np.float32))
-        w = dev(P.hwio_to_ohwi(P.glorot_uniform(rng, (3, 3, cin, cout), 9 * cin, 9 * cout)))
-        sc, sh = dev(rng.uniform(0.5, 1.5, cout).astype(np.float32)), dev(rng.uniform(-0.5, 0.5, cout).astype(np.float32))
-        nbytes = ops.conv3x3_workspace_bytes(N, H, H, cin, cout, pool)
-        assert nbytes > 0
-        ws = torch.full((nbytes // 4,), float('nan'), dtype=torch.float32, device=DEV)
-        with ops.KernelTimer() as kt:
-            first = ops.conv3x3_bn_leaky(x, w, sc, sh, pool, workspace=ws).clone()
-            torch.cuda.synchronize()
-            names = sorted(k.split('@')[0] for k in kt.table())
-        assert bool(torch.isfinite(first).all())
-        for _ in range(reps):
-            ws.fill_(float('nan'))
-            assert torch.equal(ops.conv3x3_bn_leaky(x, w, sc, sh, pool, workspace=ws), first)
-        return names
-
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    if cus != 256:
-        pytest.skip(f'the tile counts below are chosen for 256 CUs (this device: {cus})')
-    for case, reps in (((24, 28, 128, 256, True), 200), ((33, 56, 64, 128, True), 50), ((50, 112, 32, 64, True), 20), ((64, 14, 256, 512, True), 50)):
-        names = launches(*case, reps)                                   # hundreds of tiles: summed inside the one conv launch
-        assert len(names) == 1 and names[0].startswith('conv_f32_'), (case, names)
-    names = launches(12, 7, 1024, 256, False, 20)                       # 40 tiles, all tail, 16+ pieces each: second launch
-    assert len(names) == 2 and names[1] == 'conv_fixup', names
-
-
 @pytest.mark.parametrize('alpha', [0.0, 0.5, 1.0, 1.5, -0.25])
 @pytest.mark.parametrize('N,H,cin,cout,pool', [(1, 36, 3, 16, True), (1, 40, 3, 16, False), (1, 20, 16, 32, True),
                                                (2, 10, 32, 64, True), (1, 6, 64, 128, False)])

@@ -29,7 +29,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <atomic>
 #include <mutex>
 
 #ifndef TY1_STATIC_SCRATCH_BYTES
@@ -131,10 +130,6 @@ struct PersistArgs {
     const float *scale, *shift;
     void *y;             // output tensor (f32 or bf16)
     float *part;         // partial tiles of the K-split tail: [split][tail tile][BM][BN]
-    // One arrival counter per tail tile (zero before the launch, zero again after it), or nullptr.  With counters the
-    // workgroup that stores the LAST K piece of a tail tile sums the pieces (in piece order: the result does not depend
-    // on who arrives last) and runs the fused epilogue itself; without them conv_fixup_kernel does that in a second launch.
-    unsigned *tail_cnt;
     int NB, H, W, Cin, Cout, M;
     int chunks_total;
     float alpha;
@@ -182,7 +177,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
     constexpr int NS = 3 * STAGE <= TY1_NS3_LIMIT ? 3 : 2;
     constexpr int PW = TA + TB;                 // DMA instructions per wave and chunk
     __shared__ __attribute__((aligned(16))) char lds[NS * STAGE];
-    __shared__ int s_last;                      // "this workgroup stored the last K piece of its tail tile" (see PersistArgs::tail_cnt)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -204,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 
     // ---- item descriptors (block-uniform scalars)
     struct Desc {
-        int mt, nt, kc0, kc1, tap0, ci0, pslot, tail;
+        int mt, nt, kc0, kc1, tap0, ci0, pslot;
         bool live, raw;
     };
     auto decode = [&](int it) {
@@ -227,13 +221,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         d.tap0 = (int)fdiv((unsigned)d.kc0, a.d_cpt);
         d.ci0 = (d.kc0 - d.tap0 * chunks_per_tap) * BKE;
         d.pslot = split * a.rem + tail_tile;
-        d.tail = tail_tile;
         // block-uniform by construction: keep them in scalar registers
         d.mt = __builtin_amdgcn_readfirstlane(d.mt); d.nt = __builtin_amdgcn_readfirstlane(d.nt);
         d.kc0 = __builtin_amdgcn_readfirstlane(d.kc0); d.kc1 = __builtin_amdgcn_readfirstlane(d.kc1);
         d.tap0 = __builtin_amdgcn_readfirstlane(d.tap0); d.ci0 = __builtin_amdgcn_readfirstlane(d.ci0);
         d.pslot = __builtin_amdgcn_readfirstlane(d.pslot);
-        d.tail = __builtin_amdgcn_readfirstlane(d.tail);
         return d;
     };
     // ---- per-item row geometry of this thread's fetch rows (buffer offsets relative to `origin`)
@@ -308,7 +300,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = d.nt * BN + wave_n * (32 * WN) + 32 * j + (lane & 31);
-            const bool ok = d.live && (!d.raw || a.tail_cnt != nullptr) && n < a.Cout;     // (a K piece may turn out to be its tile's last)
+            const bool ok = d.live && !d.raw && n < a.Cout;
             sc[j] = ok ? a.scale[n] : 0.f;
             sh[j] = ok ? a.shift[n] : 0.f;
         }
@@ -553,64 +545,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
         //      (r&3) + 8*(r>>2) + 4*(lane>>5).
         //      Stores go through a buffer resource based at the tile's first output row: one address VGPR per
         //      tile column, rows past the end of the tensor fall outside the resource and are dropped.
-        bool fold = false;
-        if (cur.raw && a.tail_cnt) {
-            // K piece with arrival counters.  The partial tile goes to the workspace in REGISTER order - 16 bytes per lane and
-            // accumulator quad, 4 KB contiguous per store instruction - because only the workgroup that sums the pieces reads
-            // it, into the same registers.  Hand-over between workgroups without cache-wide fences (an agent-scope release
-            // writes back the whole L2: measured +40 us per layer): every store and load of these bytes carries sc1, every
-            // wave waits for its stores, then ONE lane counts the workgroup's arrival with an agent-scope atomic add; the
-            // workgroup whose add returns splits - 1 came last (MI355X_MICROARCH.md, inter-workgroup visibility, first row).
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            constexpr int kSc1 = 16;              // cache-policy bit of raw buffer loads / stores on gfx950
-            const long long tile_b = (long long)BM * BN * 4;
-            const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, (int)(tile_b * a.rem * a.splits), 0x00020000);
-            const unsigned lane_b = (unsigned)tid * 16u;
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const u32x4 v = {__float_as_uint(acc[i][j][4 * g]), __float_as_uint(acc[i][j][4 * g + 1]),
-                                         __float_as_uint(acc[i][j][4 * g + 2]), __float_as_uint(acc[i][j][4 * g + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, p_rsrc, (int)(lane_b + (unsigned)(((i * WN + j) * 4 + g) * 4096)),
-                                                               (int)(cur.pslot * tile_b), kSc1);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned before = __hip_atomic_fetch_add(a.tail_cnt + cur.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool last = before + 1u == (unsigned)a.splits;
-                if (last) __hip_atomic_store(a.tail_cnt + cur.tail, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero for the next launch
-                s_last = last ? 1 : 0;
-            }
-            __syncthreads();
-            fold = __builtin_amdgcn_readfirstlane(s_last) != 0;
-            if (fold) {
-                // sum the pieces in piece order (this workgroup's own included, from memory): the result does not depend on
-                // which piece arrived last
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                for (int sp = 0; sp < a.splits; ++sp) {
-                    const int so = (int)((long long)(sp * a.rem + cur.tail) * tile_b);
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-#pragma unroll
-                        for (int j = 0; j < WN; ++j)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(p_rsrc, (int)(lane_b + (unsigned)(((i * WN + j) * 4 + g) * 4096)), so, kSc1);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[i][j][4 * g + q] += __uint_as_float(v[q]);
-                            }
-                }
-            }
-        } else if (cur.raw) {
+        if (cur.raw) {
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 a.part + (long long)cur.pslot * (BM * BN), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
@@ -626,8 +561,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_persist_kernel
                                                               (int)(vb + (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * BN * 4)), 0, 0);
                     }
             }
-        }
-        if (!cur.raw || fold) {
+        } else {
             const int rows_out = POOL ? a.M >> 2 : a.M;
             const int r0 = POOL ? cur.mt * (BM / 4) : cur.mt * BM;
             const long long obytes = (long long)(rows_out - r0) * a.Cout * OSZ;
@@ -945,9 +879,7 @@ TailPlan plan_tail(int T, int C, int slots) {
     if (off || T % slots == 0 || C < 2) return p;
     // (measured with per-CU end-time stamps, 7x7x512->1024 at batch 64: 96 pieces left 160 CUs idle for the last 5 % of the
     //  kernel; the piece count that gives every CU the same share wins even though it is the largest split)
-    // (the last workgroup to arrive at a tail tile sums its pieces itself - fences, one atomic, a pass over s partial tiles
-    //  at one CU's bandwidth - which replaced a second launch at fix = 4.0, 0.1 per piece)
-    const double ovh = 3.0, fix = 1.5, fix_per_split = 0.25;
+    const double ovh = 3.0, fix = 4.0, fix_per_split = 0.1;
     double best = std::ceil((double)T / slots) * (C + ovh);
     const int rem = T % slots, whole = T - rem;
     static const char *hyst = ty1::dev_env("TY1_TAIL_HYST");        // developer override: required gain per step (default 0.5 %)
@@ -961,32 +893,6 @@ TailPlan plan_tail(int T, int C, int slots) {
         }
     }
     return p;
-}
-
-// Arrival counters of the K-split tail (PersistArgs::tail_cnt): a ring of kTailRing x 256 words inside the library's code
-// object, zero when it is loaded and zeroed again by the last workgroup to arrive at each counter, so a launch needs no
-// memset and allocates nothing.  Successive launches take successive ring slots: launches that overlap on one GPU (two
-// streams) do not share counters unless more than kTailRing of them are in flight.  nullptr if the address cannot be had
-// (the layer then runs its fix-up as a second launch).
-constexpr int kTailRing = 64, kTailSlots = 256;
-constexpr size_t kFoldMaxBytes = 512u << 10;
-constexpr int kFoldMinTiles = 128;
-static __device__ unsigned g_tail_counters[kTailRing * kTailSlots];
-unsigned *tail_counters(int rem) {
-    static std::atomic<unsigned *> base[64];
-    static std::atomic<unsigned> next{0};
-    static std::mutex mu;
-    int dev = -1;
-    if (rem > kTailSlots || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    unsigned *b = base[dev].load(std::memory_order_acquire);
-    if (!b) {
-        std::lock_guard<std::mutex> lock(mu);
-        void *p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tail_counters)) != hipSuccess || !p) return nullptr;
-        b = static_cast<unsigned *>(p);
-        base[dev].store(b, std::memory_order_release);
-    }
-    return b + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kTailRing) * kTailSlots;
 }
 
 // One conv layer with tile configuration <WM, WN, WAVES_M, WAVES_N, BK>: one persistent launch over the whole
@@ -1032,14 +938,6 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
         return n > 4 ? 4 : n;
     }();
     const int grid = items < occ * ty1::grid_cus() ? items : occ * ty1::grid_cus();
-    static const char *no_fold = ty1::dev_env("TY1_NO_FOLD");       // developer A/B: fix-up as a second launch
-    // ... and only while ONE workgroup can sum a tile's pieces quickly: it reads splits x BM x BN x 4 bytes at one CU's
-    // bandwidth while the chip waits, where the fix-up launch spreads them over every CU
-    static const char *fold_kb = ty1::dev_env("TY1_FOLD_MAX_KB");   // developer sweep
-    const size_t fold_max = fold_kb ? (size_t)atoi(fold_kb) << 10 : kFoldMaxBytes;
-    static const char *fold_mt = ty1::dev_env("TY1_FOLD_MIN_TILES");
-    const int fold_min_tiles = fold_mt ? atoi(fold_mt) : kFoldMinTiles;
-    a.tail_cnt = (p.rem && !no_fold && T >= fold_min_tiles && (size_t)p.splits * BM * BN * sizeof(float) <= fold_max) ? tail_counters(p.rem) : nullptr;
     a.stamp = (g_stamp && grid <= g_stamp_cap) ? g_stamp : nullptr;
     static const char *dbg = ty1::dev_env("TY1_DBG");
     a.dbg = dbg ? atoi(dbg) : 0;
@@ -1053,7 +951,7 @@ int run_conv(const char *name, const ConvArgs &c, float *ws, size_t ws_bytes, si
         conv_persist_kernel<WM, WN, WAVES_M, WAVES_N, BK, POOL, OP, OUT_BF16><<<grid, 64 * WAVES_M * WAVES_N, 0, s>>>(a);
         if (int rc = ty1::check_launch(name)) return rc;
     }
-    if (p.rem && !a.tail_cnt) {
+    if (p.rem) {
         snprintf(tag, sizeof tag, "conv_fixup@%dx%d>%d", c.H, c.Cin, c.Cout);
         ty1::ProfScope prof(tag, s, 0.0, (double)need + 4.0 * p.rem * BM * BN / (POOL ? 4 : 1));
         conv_fixup_kernel<BM, BN, POOL, OUT_BF16><<<dim3(p.rem, BM * BN / 4 / 256 < 32 ? BM * BN / 4 / 256 : 32), 256, 0, s>>>(ws, c.scale, c.shift, c.y, c.M, c.Cout, a.ntiles, a.mtiles, a.mt_fastest, p.whole,
