@@ -17,6 +17,7 @@ same process right after the headline (skip with --no-also):
 Either can be made the headline instead: --mode infer --dtype bf16, or --mode train.
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -134,12 +135,27 @@ def settle(ctx, step, settle_ms, est_step_ms):
 
 def timed(ctx, step, k):
     """Exactly k steps between barrier + synchronise on both sides; MAX over ranks."""
+    ta = time.perf_counter()
     ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(k):
-        step()
-    ctx.sync()
-    return ctx.max_over_ranks(time.perf_counter() - t0)
+    # the cyclic collector stays out of the region (as timeit does): with torch imported a full collection holds the host
+    # for ~40 ms, and where the allocation counter trips depends on nothing the step does (tools/experiments/default_stall_hunt.sh)
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for i in range(k):
+            step()
+            if i == 0:
+                t1 = time.perf_counter()
+        t2 = time.perf_counter()
+        ctx.sync()
+        t3 = time.perf_counter()
+    finally:
+        if gc_was_on:
+            gc.enable()
+    if os.environ.get('TY1_BENCH_TRACE'):
+        print(f'[trace] timed({k}): sync before {1e3 * (t0 - ta):.1f} ms, first step {1e3 * (t1 - t0):.1f} ms, enqueue {1e3 * (t2 - t0):.1f} ms, drain {1e3 * (t3 - t2):.1f} ms', file=sys.stderr, flush=True)
+    return ctx.max_over_ranks(t3 - t0)
 
 
 def families(table):
@@ -214,11 +230,18 @@ def measure(ctx, step, args, dtype, mode, est_step_ms, detailed=True):
         # survey pass (untimed): every library launch brackets itself with HIP events on its own stream -> per-kernel
         # table, names the dominant kernel.  Bracketing EVERY launch costs ~5 % of a step, so the timed region below
         # keeps the brackets on the dominant kernel's launches only.
+        tr_ = os.environ.get('TY1_BENCH_TRACE')
+        tm = [time.perf_counter()]
         with ops.KernelTimer() as kt:
             for _ in range(args.steps):
                 step()
+            tm.append(time.perf_counter())
             ctx.sync()
+            tm.append(time.perf_counter())
             table = kt.table()
+            tm.append(time.perf_counter())
+        if tr_:
+            print(f'[trace] survey pass: enqueue {1e3 * (tm[1] - tm[0]):.1f} ms, drain {1e3 * (tm[2] - tm[1]):.1f} ms, table {1e3 * (tm[3] - tm[2]):.1f} ms', file=sys.stderr, flush=True)
         fam = families(table)
         dom_name = max(fam, key=lambda k: fam[k]['ms'])
     prefix = None
@@ -510,6 +533,19 @@ def main():
     ap.add_argument('--force-gather', action='store_true',
                     help='developer check: run the N>1 code path (process group, detection gather, all-reduce) on one rank')
     args = ap.parse_args()
+    if os.environ.get('TY1_BENCH_TRACE'):               # developer aid: full collections of the cyclic collector, with their duration
+        gc_t = {}
+
+        def gc_note(phase, info):
+            if info.get('generation') == 2:
+                if phase == 'start':
+                    gc_t['t'] = time.perf_counter()
+                else:
+                    print(f'[trace] full gc: {1e3 * (time.perf_counter() - gc_t.get("t", 0.0)):.1f} ms, collected {info.get("collected")}', file=sys.stderr, flush=True)
+        gc.callbacks.append(gc_note)
+    if not os.environ.get('TY1_BENCH_NO_GC_FREEZE'):
+        gc.collect()
+        gc.freeze()          # everything imported so far (torch: ~10^6 objects) leaves the collector's generations for good
     if os.environ.get('TY1_BENCH_WATCHDOG'):          # developer aid: dump every thread's stack if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['TY1_BENCH_WATCHDOG']), repeat=True, file=sys.stderr)
