@@ -410,7 +410,7 @@ def run_train(ctx, args, N, detailed=True):
             while True:
                 time.sleep(float(os.environ['TY1_BENCH_WATCHDOG']) / 2)
                 print(f'[rank {ctx.rank}] probe at {time.perf_counter() - t_start:.1f} s: step {state.get("i", 0)} compute stream idle={cur.query()} '
-                      f'side stream idle={tr.side.query() if tr.side else None} grads_ready={tr._grads_ready.query()} '
+                      f'side stream idle={tr.side.query() if tr.side else None} feats_ready={tr._feats_ready.query()} feats_free={tr._feats_free.query()} '
                       f'updated={tr._updated.query()} pending={tr._pending} adam_deferred={tr._adam_deferred}', file=sys.stderr, flush=True)
         threading.Thread(target=probe, daemon=True).start()
 

@@ -282,6 +282,45 @@ def test_reserved_cus_change_grids_not_results():
         ops.set_reserved_cus(-1)
 
 
+def test_tail_on_the_side_stream_same_bits_and_buffers_refilled_in_place():
+    """step(wait=False) with the whole trainable tail (Dense forward, loss, gradients, update) in flight on the side stream
+    under the next batch's backbone against the same steps with the tail on the compute stream (Trainer.tail_on_side =
+    False) and against the serial trainer: same losses, weights and moments, bit for bit, over 4 steps at 8 images -
+    also when the caller refills ONE image buffer and ONE label buffer in place as soon as step() has returned (the tail
+    reads a private copy of the labels; the feature buffer is handed back through an event inside the next backbone)."""
+    N = 8
+    prm = P.make_random_params(seed=6, dense_init='glorot', bn='random')
+    xs = [torch.rand((N, 448, 448, 3), generator=torch.Generator().manual_seed(60 + i)).to(DEV) for i in range(4)]
+    ys = [torch.from_numpy(_labels(N, 20, 70 + i)).to(DEV) for i in range(4)]
+
+    def run(mode):
+        model = DeviceModel(prm, device=DEV)
+        tr = Trainer(model, lr=1e-5, overlap=(mode != 'serial'))
+        tr.tail_on_side = mode in ('side', 'side, in place')
+        losses = []
+        if mode == 'side, in place':
+            xb, yb = torch.empty_like(xs[0]), torch.empty_like(ys[0])
+            for x, y in zip(xs, ys):
+                xb.copy_(x)
+                yb.copy_(y)
+                losses.append(tr.step(xb, yb, wait=False))
+                xb.fill_(0.5)                 # the caller's buffers are its own again
+                yb.zero_()
+        else:
+            for x, y in zip(xs, ys):
+                losses.append(tr.step(x, y, wait=(mode == 'serial')))
+        tr.join()
+        torch.cuda.synchronize()
+        return torch.cat(losses).cpu(), tr.pflat.clone().cpu(), tr.m.clone().cpu(), tr.v.clone().cpu()
+
+    want = run('serial')
+    assert torch.isfinite(want[0]).all() and want[0][3] < want[0][0]
+    for mode in ('compute', 'side', 'side, in place'):
+        got = run(mode)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), mode
+
+
 def test_overlapped_step_equals_serial_step_one_rank_rccl():
     """The step with its single all-reduce + Adam on a side stream, overlapped with the next batch's frozen backbone
     (wait=False), gives the same bits as the serial step, over 3 steps, through RCCL (backend nccl) on one rank; and the

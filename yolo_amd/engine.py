@@ -173,14 +173,17 @@ class Trainer:
     (Keras defaults) updates the only trainable parameters: the Dense kernel and bias (Q8).
 
     Exchange and update are built to scale: [dWt | db | loss] is one flat buffer (parallel.GradBucket) = ONE all-reduce
-    per step, the parameters and Adam moments use the same [Wt | b] order = ONE Adam launch, and with overlap=True both
-    run on a side stream while the compute stream already runs the NEXT batch's backbone - legal because every conv
+    per step, the parameters and Adam moments use the same [Wt | b] order = ONE Adam launch.  With overlap=True the
+    whole trainable tail - Dense forward, head + loss + head Jacobian, weight gradient, all-reduce, Adam - runs on a
+    side stream, in order, while the compute stream already runs the NEXT batch's backbone: legal because every conv
     and BatchNormalization layer is frozen (/root/reference/models/model_tiny_yolov1.py:43-87, trainable=False), so
-    the backbone does not read anything the update writes.  The compute stream waits for the update only where it
-    needs the new Dense weights: in front of the next Dense forward (step(..., wait=False)), or at the end of the
-    step (wait=True, the default: the returned loss and the weights are then ordered on the caller's stream)."""
+    the backbone reads nothing the tail writes, and the side stream's order alone puts step i+1's Dense forward behind
+    step i's update.  The only edge back: the next backbone's last layer overwrites the feature buffer, so the compute
+    stream waits (in the middle of that backbone, long after the fact) for the tail to have read it.  step(wait=True),
+    the default, ends with join(): loss and weights are then ordered on the caller's stream.  The arithmetic and its
+    order are those of the serial step: same bits (tests/test_gpu_api.py)."""
 
-    UPDATE_AFTER_LAYER = 4        # 14x14x256->512: in-call A/B tools/experiments/adam_defer_ab.sh, 1.050 -> 1.030 ms per step at 32 images
+    UPDATE_AFTER_LAYER = 2        # 112x112x32->64: in-call A/B tools/experiments/tail_side_ab.sh at 32 images (ms per step): at once 0.977, after layer 0 / 1 / 2 / 3 / 4 / 5: 0.979 / 1.004 / 0.971 / 0.977 / 0.973 / 0.988
 
     def __init__(self, model, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, group=None, overlap=True):
         if model.dtype != 'f32':
@@ -204,17 +207,21 @@ class Trainer:
         self.ldz = ops.round_up(model.units, 4)
         self._dz = {}
         self.side = torch.cuda.Stream(dev) if overlap else None
-        self._grads_ready = torch.cuda.Event()
+        self._feats_ready = torch.cuda.Event()   # compute stream: the backbone's features are written
+        self._feats_free = torch.cuda.Event()    # side stream: Dense forward and weight gradient have read them
+        self._y = {}                             # private label buffers of step(wait=False), by shape
         self._updated = torch.cuda.Event()
         self._pending = False            # an update is in flight on the side stream
         self.collective_events = None    # (start, end) CUDA events around the last all-reduce when time_collective is set
         self.time_collective = False
         self.skip_collective = False     # measurement only (bench: step time without the exchange)
+        self.tail_on_side = True         # False: Dense forward / loss / weight gradient on the compute stream (same bits; A/B)
         self.fused_tail = True           # False: the three separate launches (same bits; kept for the comparison test)
         # step(wait=False) only: the Adam launch of the update in flight is held back until the NEXT batch's backbone has
         # enqueued this layer (None: it follows the all-reduce at once).  The first two layers are bound by their own
         # instruction streams and by HBM, and the 516 MB Adam pass next to them costs them more than it hides; under the
-        # MFMA-bound layers behind them it is nearly free.  The all-reduce itself always starts at once.
+        # MFMA-bound layers behind them it costs the step 30 of its 85 us (tools/experiments/tail_knockouts.sh).  The
+        # all-reduce itself always starts at once.
         self.update_after_layer = Trainer.UPDATE_AFTER_LAYER
         self._adam_deferred = False
         # CUs the NEXT batch's persistent conv grids leave free while this step's exchange is in flight (ty1_set_reserved_cus):
@@ -232,6 +239,10 @@ class Trainer:
         that the next call (or the next collective) overwrites - clone it to keep it.  An update still in flight on the
         side stream (step(wait=False)) is joined first: it reads the bucket this call writes."""
         self.join()
+        return self._tail(feats, y_true)
+
+    def _tail(self, feats, y_true):
+        """Dense forward, head + loss + head Jacobian, Dense weight gradient: enqueued on the CURRENT stream."""
         m = self.model
         N = feats.shape[0]
         ws = m.workspace(N)
@@ -248,6 +259,13 @@ class Trainer:
             ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
         ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
         return self.bucket.loss
+
+    def _mid_backbone(self):
+        """Runs on the host once the next batch's backbone has enqueued layer `update_after_layer`: from here on the compute
+        stream may overwrite the feature buffer (the tail in flight has read it), and the held-back Adam launch goes out."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_event(self._feats_free)
+        self._launch_deferred_adam()
 
     def _launch_deferred_adam(self):
         """The held-back Adam launch: on the side stream, behind the all-reduce already there and behind whatever the
@@ -297,25 +315,46 @@ class Trainer:
 
     def step(self, x, y_true, wait=True):
         """x (n,448,448,3), y_true (n,S,S,C+5) on the device -> global batch loss (1,) on the device.
-        wait=False leaves the exchange + update in flight on the side stream (the next step() or join() waits for it
-        in front of its Dense forward); the returned loss is then valid only after join() / a device synchronise."""
-        hook = (self.update_after_layer, self._launch_deferred_adam) if self._adam_deferred else None
+        wait=False leaves everything behind the backbone - Dense forward, loss, gradients, exchange, update - in flight on
+        the side stream, in order behind the previous step's update; the next step() puts its backbone on the compute stream
+        at once.  The returned loss is then valid only after join() / a device synchronise; y_true is copied before the
+        call returns, so the caller may refill it."""
+        if self.side is None:
+            feats = self.model.backbone(x, self.model.workspace(x.shape[0]))
+            self._tail(feats, y_true)
+            return self._exchange_and_update()
+        cur = torch.cuda.current_stream(self.device)
+        hook = None
+        if self._pending:
+            # the tail in flight reads the feature buffer this backbone's LAST layer writes: the hook must run before that
+            last = len(self.model.conv) - 2
+            hook = (last if self.update_after_layer is None else min(self.update_after_layer, last), self._mid_backbone)
         shrink = self.reserve_cus > 0 and self._pending
         if shrink:
             ops.set_reserved_cus(self.reserve_cus)
         try:
-            feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the update in flight
+            feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the tail + update in flight
         finally:
             if shrink:
                 ops.set_reserved_cus(0)
-        self.join()
-        self.gradients_from_features(feats, y_true)
-        if self.side is None:
-            return self._exchange_and_update()
-        cur = torch.cuda.current_stream(self.device)
-        self._grads_ready.record(cur)
+        self._mid_backbone()                   # (a backbone shorter than the hook's layer: nothing has waited yet)
+        if not self.tail_on_side:              # round-2 order, kept for the A/B: the tail on the compute stream, behind the update
+            self.join()
+            self._tail(feats, y_true)
+        elif not wait:
+            # the side stream reads the labels after this call has returned: a private copy (157 KB at 32 images), made
+            # here - behind the wait for the previous tail, which read the same buffer
+            yb = self._y.get(y_true.shape)
+            if yb is None:
+                yb = self._y[y_true.shape] = torch.empty_like(y_true)
+            yb.copy_(y_true)
+            y_true = yb
+        self._feats_ready.record(cur)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(self._grads_ready)
+            self.side.wait_event(self._feats_ready)
+            if self.tail_on_side:
+                self._tail(feats, y_true)
+            self._feats_free.record(self.side)
             defer = not wait and self.update_after_layer is not None
             loss = self._exchange_and_update(defer_adam=defer)
             if not defer:
