@@ -393,8 +393,12 @@ def run_train(ctx, args, N, detailed=True):
     C = 20
     prm = P.make_random_params(seed=1, C=C, dense_init='glorot', bn='identity')
     model = DeviceModel(prm, C=C, device=ctx.dev)
-    x = synthetic_images(N, 100 + ctx.rank, ctx.dev).to(ctx.dev)
-    yd = torch.from_numpy(make_labels(N, C, 3 + ctx.rank)).to(ctx.dev)
+    # G consecutive batches share ONE pass of the frozen backbone (Trainer.steps): G x N images through the conv layers at
+    # once, then G optimisation steps of N images each.  A bench step stays one optimisation step: every G-th call of step()
+    # enqueues G of them, so any region of K calls (K a multiple of G) holds exactly K.
+    G = args.train_group if args.train_group > 0 and args.steps % max(args.train_group, 1) == 0 else 1
+    x = synthetic_images(G * N, 100 + ctx.rank, ctx.dev).to(ctx.dev)
+    yd = torch.from_numpy(make_labels(G * N, C, 3 + ctx.rank)).to(ctx.dev)
     tr = Trainer(model, group=None, overlap=not args.no_overlap)
     if args.update_after_layer is not None:
         tr.update_after_layer = None if args.update_after_layer < 0 else args.update_after_layer
@@ -415,7 +419,9 @@ def run_train(ctx, args, N, detailed=True):
         threading.Thread(target=probe, daemon=True).start()
 
     def step():
-        state['loss'] = tr.step(x, yd, wait=False)     # exchange + Adam stay in flight under the next backbone
+        state['calls'] = state.get('calls', 0) + 1
+        if state['calls'] % G == 0:
+            state['loss'] = tr.steps(x, yd, N, wait=False)[-1:]     # tail, exchange + Adam stay in flight under the next backbone
         if trace:
             state['i'] = state.get('i', 0) + 1
             print(f'[rank {ctx.rank}] train step {state["i"]} done at {time.perf_counter() - t_start:.3f} s', file=sys.stderr, flush=True)
@@ -441,6 +447,13 @@ def run_train(ctx, args, N, detailed=True):
             step()
         no_coll = timed(ctx, step, K)
         tr.skip_collective = False
+        one_per_batch = None
+        if G > 1:                      # the same K steps with one backbone pass per batch (Trainer.step), for comparison
+            x1, y1 = x[:N], yd[:N]
+            step1 = lambda: tr.step(x1, y1, wait=False)
+            for _ in range(10):
+                step1()
+            one_per_batch = timed(ctx, step1, K)
     finally:
         ctx.sync = real_sync
     nbytes = tr.bucket.nbytes()
@@ -451,8 +464,10 @@ def run_train(ctx, args, N, detailed=True):
         'ms_per_step': round(1e3 * m['elapsed'] / K, 4), 'settle_steps': m['settle_steps'], 'dtype': 'f32',
         'config': {'workload': f'configs[3]: tiny-YOLOv1 VOC-20 training step, batch={N}/GPU fp32: frozen backbone fwd + Dense + '
                                'head + yolo_loss fwd/bwd + head bwd + Dense wgrad + ONE SUM all-reduce [dWt|db|loss] + Adam; '
-                               'random-init weights, torch.rand images and synthetic labels resident in HBM',
-                   'global_batch': world * N, 'per_gpu_batch': N,
+                               'random-init weights, torch.rand images and synthetic labels resident in HBM'
+                               + (f'; the frozen backbone runs once per {G} consecutive batches ({G * N} images), every batch of {N} '
+                                  'then takes its own optimisation step (Trainer.steps)' if G > 1 else ''),
+                   'global_batch': world * N, 'per_gpu_batch': N, 'batches_per_backbone_pass': G,
                    'sharding': 'batch split across ranks (data parallel), gradients summed (no division: the loss is a batch sum)',
                    'overlap': 'all-reduce + Adam on a side stream under the next batch\'s frozen backbone'
                               if not args.no_overlap else 'serial'},
@@ -467,6 +482,9 @@ def run_train(ctx, args, N, detailed=True):
         'cold_start_images_per_sec': round(world * N * K / m['cold'], 1),
         'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS['f32'] * 1e12), 4),
     }
+    if one_per_batch is not None:
+        res['one_backbone_pass_per_batch'] = {'images_per_sec': round(world * N * K / one_per_batch, 1), 'ms_per_step': round(1e3 * one_per_batch / K, 4),
+                                              'note': 'Trainer.step per batch, un-instrumented, same process'}
     if ctx.multi:
         res['rccl'] = {'backend': 'nccl (RCCL)' if ctx.backend == 'nccl' else ctx.backend, 'world_size_reported': ctx.rccl_world}
     if 'roofline' in m:
@@ -525,6 +543,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='inference: replay the step as one HIP graph (DeviceModel.detect_replay)')
     ap.add_argument('--update-after-layer', type=int, default=None,
                     help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')
+    ap.add_argument('--train-group', type=int, default=2,
+                    help='training: consecutive batches that share one pass of the frozen backbone (Trainer.steps); 1 = Trainer.step per batch')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')
     ap.add_argument('--settle-ms', type=float, default=200.0, help='untimed steps after the warm-up until the clocks have settled')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],

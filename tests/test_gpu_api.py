@@ -321,6 +321,50 @@ def test_tail_on_the_side_stream_same_bits_and_buffers_refilled_in_place():
             assert torch.equal(a, b), mode
 
 
+def test_steps_frozen_backbone_once_over_consecutive_batches():
+    """Trainer.steps(x, y, batch): the frozen backbone once over k = 3 consecutive batches of 8 images, then 3 optimisation
+    steps in order.  (a) the overlapped form (everything behind the backbone on the side stream, twice in a row with
+    wait=False, buffers refilled in place) gives the bits of the serial trainer's steps(); (b) against 6 separate
+    step() calls - whose backbones run at 8 images, with other K-split plans - the losses agree to 1e-5 relative and the
+    weights to the bar of test_training_step_vs_torch_reference (Adam's step is a sign function at rounding level)."""
+    b, k = 8, 3
+    prm = P.make_random_params(seed=6, dense_init='glorot', bn='random')
+    xs = [torch.rand((k * b, 448, 448, 3), generator=torch.Generator().manual_seed(80 + i)).to(DEV) for i in range(2)]
+    ys = [torch.from_numpy(_labels(k * b, 20, 90 + i)).to(DEV) for i in range(2)]
+
+    def run(mode):
+        model = DeviceModel(prm, device=DEV)
+        tr = Trainer(model, lr=1e-5, overlap=(mode == 'overlap'))
+        losses = []
+        if mode == 'overlap':
+            xb, yb = torch.empty_like(xs[0]), torch.empty_like(ys[0])
+            for x, y in zip(xs, ys):
+                xb.copy_(x)
+                yb.copy_(y)
+                losses.append(tr.steps(xb, yb, b, wait=False))
+                xb.fill_(0.5)
+                yb.zero_()
+        elif mode == 'serial':
+            losses = [tr.steps(x, y, b) for x, y in zip(xs, ys)]
+        else:
+            losses = [tr.step(x[j * b:(j + 1) * b].contiguous(), y[j * b:(j + 1) * b].contiguous()) for x, y in zip(xs, ys) for j in range(k)]
+        tr.join()
+        torch.cuda.synchronize()
+        assert tr.t == 2 * k
+        return torch.cat(losses).cpu(), tr.pflat.clone().cpu(), tr.m.clone().cpu()
+
+    serial, overlap, single = run('serial'), run('overlap'), run('single')
+    assert serial[0].shape == (2 * k,) and torch.isfinite(serial[0]).all()
+    for a, c in zip(serial, overlap):
+        assert torch.equal(a, c)
+    torch.testing.assert_close(serial[0], single[0], rtol=1e-5, atol=0)
+    diff = (serial[1] - single[1]).abs()
+    assert (diff > 2e-5 + 1e-3 * single[1].abs()).float().mean() < 1e-5 and diff.max() <= 2 * k * 1.1e-5
+    model = DeviceModel(prm, device=DEV)
+    with pytest.raises(ValueError, match='do not split'):
+        Trainer(model).steps(xs[0], ys[0], 7)
+
+
 def test_overlapped_step_equals_serial_step_one_rank_rccl():
     """The step with its single all-reduce + Adam on a side stream, overlapped with the next batch's frozen backbone
     (wait=False), gives the same bits as the serial step, over 3 steps, through RCCL (backend nccl) on one rank; and the

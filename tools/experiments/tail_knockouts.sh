@@ -53,36 +53,34 @@ def plumbing(name, steps=200):
     tr.join(); torch.cuda.synchronize()
     print(f'all four gone, {name:40}: {(time.perf_counter() - t0) / steps * 1e3:.4f} ms')
 plumbing('as is')
-real_mid = tr._mid_backbone
-tr._mid_backbone = lambda: None
-plumbing('no wait for the features, no gate')
-tr._mid_backbone = lambda: tr._launch_deferred_adam()
-plumbing('no wait for the features (gate stays)')
-def only_wait():
-    if tr._pending:
-        torch.cuda.current_stream(dev).wait_event(tr._feats_free)
+real_back, real_gate = tr._take_features_back, tr._launch_deferred_adam
+def ungated():
     if tr._adam_deferred:
         tr._adam_deferred = False
         with torch.cuda.stream(tr.side):
             tr._adam()
             tr._updated.record(tr.side)
-tr._mid_backbone = only_wait
+tr._take_features_back = lambda: None
+plumbing('no wait for the features (gate stays)')
+tr._take_features_back, tr._launch_deferred_adam = real_back, ungated
 plumbing('no gate (wait stays)')
-tr._mid_backbone = real_mid
+tr._take_features_back = lambda: None
+plumbing('no wait for the features, no gate')
+tr._take_features_back, tr._launch_deferred_adam = real_back, real_gate
 for ual in (0, 1, 3, 4, 5, 6, 2):
     tr.update_after_layer = ual
-    plumbing(f'as is, hook after layer {ual}')
+    plumbing(f'as is, Adam gate after layer {ual}')
 real_clone = torch.Tensor.clone
 real_copy = torch.Tensor.copy_
 torch.Tensor.copy_ = lambda self, other, *a, **k: self
 plumbing('no label copy')
-tr._mid_backbone = lambda: None
+tr._take_features_back, tr._launch_deferred_adam = (lambda: None), ungated
 plumbing('no label copy, no wait, no gate')
 torch.Tensor.clone = lambda self, *a, **k: self
 tr.bucket.loss.record_stream = lambda s: None
 plumbing('... and no loss clone')
 torch.Tensor.clone, torch.Tensor.copy_ = real_clone, real_copy
-tr._mid_backbone = real_mid
+tr._take_features_back, tr._launch_deferred_adam = real_back, real_gate
 t0 = time.perf_counter()
 for _ in range(200):
     model.backbone(x, ws)

@@ -27,24 +27,20 @@ def run(side, ual, steps=200):
 for _ in range(300):
     tr.step(x, yd, wait=False)
 tr.join(); torch.cuda.synchronize()
-cases = [(False, 4), (True, 4), (True, 2), (True, 1), (True, 0), (True, 3)]
-res = {c: [] for c in cases}
-for _ in range(4):
-    for c in cases:
-        res[c].append(run(*c))
-def backbone_only(steps=200):
-    ws = model.workspace(N)
-    for _ in range(10):
-        model.backbone(x, ws)
-    torch.cuda.synchronize()
+xg = {g: bench.synthetic_images(g * N, 100, dev).to(dev) for g in (2, 4)}
+yg = {g: torch.from_numpy(bench.make_labels(g * N, 20, 3)).to(dev) for g in (2, 4)}
+def run_group(g, steps=200):
+    tr.tail_on_side, tr.update_after_layer = True, 2
+    xx, yy = (x, yd) if g == 1 else (xg[g], yg[g])
+    for _ in range(6):
+        tr.steps(xx, yy, N, wait=False)
+    tr.join(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        model.backbone(x, ws)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
-tr.join(); torch.cuda.synchronize()
-print('backbone alone:', [round(backbone_only(), 4) for _ in range(3)], 'ms')
-for c in cases:
-    m = statistics.median(res[c])
-    print(f'tail_on_side={c[0]!s:5} update_after_layer={c[1]!s:4}: {m:.4f} ms  {N / m * 1e3:.0f} images/s   {[round(v, 4) for v in res[c]]}')
+    for _ in range(steps // g):
+        tr.steps(xx, yy, N, wait=False)
+    tr.join(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (steps // g * g) * 1e3
+for g in (1, 2, 4, 1, 2, 4):
+    m = run_group(g)
+    print(f'backbone once per {g} batches of {N}: {m:.4f} ms per optimisation step  {N / m * 1e3:.0f} images/s')
 PY

@@ -71,13 +71,14 @@ class DeviceModel:
     # ------------------------------------------------------------------ forward pieces
     def backbone(self, x, ws=None, after_layer=None):
         """x (N,H,W,3) f32 NHWC on the device -> features (N, 12544) (HWC flatten).
-        after_layer: optional (index, callable) - the callable runs on the host once layer `index` has been enqueued
-        (the trainer uses it to start the deferred Adam launch under the compute-bound layers)."""
+        after_layer: optional {index: callable} - a callable runs on the host once layer `index` has been enqueued (the
+        trainer uses it to start the deferred Adam launch under the compute-bound layers and to take the feature buffer
+        back from the tail in flight before the last layer writes it)."""
         ws = ws or self.workspace(x.shape[0])
         fused01 = self.fused01 and self._fusable01(x)
         for i, (layer, out) in enumerate(zip(self.conv, ws['acts'])):
-            if after_layer is not None and i == after_layer[0] + 1:
-                after_layer[1]()
+            if after_layer and i - 1 in after_layer:
+                after_layer[i - 1]()
             if fused01 and i < 2:          # blocks 0 and 1 of the bf16 network are one launch: the tensor between them stays in LDS
                 if i == 1:
                     l0 = self.conv[0]
@@ -260,12 +261,11 @@ class Trainer:
         ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
         return self.bucket.loss
 
-    def _mid_backbone(self):
-        """Runs on the host once the next batch's backbone has enqueued layer `update_after_layer`: from here on the compute
-        stream may overwrite the feature buffer (the tail in flight has read it), and the held-back Adam launch goes out."""
+    def _take_features_back(self):
+        """The tail in flight reads the feature buffer the backbone's LAST layer writes: the compute stream waits for it
+        to have done so (enqueued right before that layer: by then the tail is long past it)."""
         if self._pending:
             torch.cuda.current_stream(self.device).wait_event(self._feats_free)
-        self._launch_deferred_adam()
 
     def _launch_deferred_adam(self):
         """The held-back Adam launch: on the side stream, behind the all-reduce already there and behind whatever the
@@ -292,8 +292,9 @@ class Trainer:
         self.t += 1
         ops.adam_step(self.pflat, self.bucket.grads, self.m, self.v, self.t, self.lr, self.beta1, self.beta2, self.eps)
 
-    def _exchange_and_update(self, defer_adam=False):
-        """ONE all-reduce of the bucket, the global loss copied out, ONE Adam launch - on the current stream."""
+    def _exchange_and_update(self, defer_adam=False, loss_out=None):
+        """ONE all-reduce of the bucket, the global loss copied out (into loss_out (1,) if given), ONE Adam launch - on the
+        current stream."""
         if not self.skip_collective:
             if self.time_collective:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -306,7 +307,7 @@ class Trainer:
             if self.time_collective:
                 e1.record()
                 self.collective_events = (e0, e1)
-        loss = self.bucket.loss.clone()
+        loss = self.bucket.loss.clone() if loss_out is None else loss_out.copy_(self.bucket.loss)
         if defer_adam:
             self._adam_deferred = True
         else:
@@ -319,29 +320,42 @@ class Trainer:
         the side stream, in order behind the previous step's update; the next step() puts its backbone on the compute stream
         at once.  The returned loss is then valid only after join() / a device synchronise; y_true is copied before the
         call returns, so the caller may refill it."""
+        return self.steps(x, y_true, x.shape[0], wait)
+
+    def steps(self, x, y_true, batch, wait=True):
+        """k = n / batch consecutive optimisation steps on x (n,448,448,3), y_true (n,S,S,C+5): the FROZEN backbone runs once
+        over all n images - it does not depend on anything the steps change, and its kernels run closer to their peak on 64
+        or 128 images than on 32 - then each batch of `batch` images gets its own Dense forward, loss, gradient, exchange
+        and Adam update, in order, exactly as k calls of step() would (the features of an image may differ from those of a
+        smaller launch in the last bits: other K-split plans).  -> the k global batch losses (k,).  wait as in step()."""
+        n, b = x.shape[0], int(batch)
+        if b <= 0 or n % b or y_true.shape[0] != n:
+            raise ValueError(f'steps: {n} images / {y_true.shape[0]} label rows do not split into batches of {b}')
+        k = n // b
+        part = lambda t, j: t[j * b:(j + 1) * b]
         if self.side is None:
-            feats = self.model.backbone(x, self.model.workspace(x.shape[0]))
-            self._tail(feats, y_true)
-            return self._exchange_and_update()
+            feats = self.model.backbone(x, self.model.workspace(n))
+            losses = []
+            for j in range(k):
+                self._tail(part(feats, j), part(y_true, j))
+                losses.append(self._exchange_and_update())
+            return torch.cat(losses)
         cur = torch.cuda.current_stream(self.device)
-        hook = None
+        hooks = {}
         if self._pending:
-            # the tail in flight reads the feature buffer this backbone's LAST layer writes: the hook must run before that
             last = len(self.model.conv) - 2
-            hook = (last if self.update_after_layer is None else min(self.update_after_layer, last), self._mid_backbone)
+            gate = last if self.update_after_layer is None else min(self.update_after_layer, last)
+            hooks[gate] = self._launch_deferred_adam
+            hooks[last] = (lambda: (self._take_features_back(), self._launch_deferred_adam())) if gate == last else self._take_features_back
         shrink = self.reserve_cus > 0 and self._pending
         if shrink:
             ops.set_reserved_cus(self.reserve_cus)
         try:
-            feats = self.model.backbone(x, self.model.workspace(x.shape[0]), hook)   # frozen: overlaps the tail + update in flight
+            feats = self.model.backbone(x, self.model.workspace(n), hooks)   # frozen: overlaps the tail + update in flight
         finally:
             if shrink:
                 ops.set_reserved_cus(0)
-        self._mid_backbone()                   # (a backbone shorter than the hook's layer: nothing has waited yet)
-        if not self.tail_on_side:              # round-2 order, kept for the A/B: the tail on the compute stream, behind the update
-            self.join()
-            self._tail(feats, y_true)
-        elif not wait:
+        if self.tail_on_side and not wait:
             # the side stream reads the labels after this call has returned: a private copy (157 KB at 32 images), made
             # here - behind the wait for the previous tail, which read the same buffer
             yb = self._y.get(y_true.shape)
@@ -349,18 +363,25 @@ class Trainer:
                 yb = self._y[y_true.shape] = torch.empty_like(y_true)
             yb.copy_(y_true)
             y_true = yb
-        self._feats_ready.record(cur)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self._feats_ready)
-            if self.tail_on_side:
-                self._tail(feats, y_true)
-            self._feats_free.record(self.side)
-            defer = not wait and self.update_after_layer is not None
-            loss = self._exchange_and_update(defer_adam=defer)
-            if not defer:
-                self._updated.record(self.side)
-        loss.record_stream(cur)
-        self._pending = True
+        losses = torch.empty((k,), dtype=torch.float32, device=self.device)    # written on the side stream, slot by slot
+        losses.record_stream(self.side)
+        for j in range(k):
+            if not self.tail_on_side:          # round-2 order, kept for the A/B: the tail on the compute stream, behind the update
+                self.join()
+                self._tail(part(feats, j), part(y_true, j))
+            self._feats_ready.record(cur)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self._feats_ready)
+                if self.tail_on_side:
+                    self._tail(part(feats, j), part(y_true, j))
+                if j == k - 1:
+                    self._feats_free.record(self.side)
+                # only the last update can wait for the next backbone: the next Dense forward needs the others at once
+                defer = j == k - 1 and not wait and self.update_after_layer is not None
+                self._exchange_and_update(defer_adam=defer, loss_out=losses[j:j + 1])
+                if not defer:
+                    self._updated.record(self.side)
+            self._pending = True
         if wait:
             self.join()
-        return loss
+        return losses
