@@ -425,6 +425,23 @@ def test_keras_style_training_entry_points(tmp_path):
 
     hist = model.fit_generator(Gen(), steps_per_epoch=2, epochs=2, validation_data=Gen(), validation_steps=1, verbose=0)
     assert hist['loss'][1] < hist['loss'][0] and len(hist['val_loss']) == 2
+    # fit_generator pairs consecutive batches for one pass of the frozen backbone (a ragged last batch steps alone) and keeps
+    # the losses on the device: the same epoch through train_on_batch, one host round trip per step, must agree
+    class Ragged:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            return (x, y) if i < 2 else (x[:2], y[:2])
+
+    ma, mb = (Model(inputs=inputs, outputs=outputs, seed=7) for _ in range(2))
+    for m in (ma, mb):
+        m.compile(loss=yolo_loss, optimizer=Adam(lr=1e-5))
+    ha = ma.fit_generator(Ragged(), epochs=1, verbose=0)
+    lb = [mb.train_on_batch(*Ragged()[i]) for i in range(3)]
+    assert abs(ha['loss'][0] - sum(lb) / 3) <= 1e-5 * abs(sum(lb) / 3)
+    wa, wb = ma.engine.dense_wt.cpu(), mb.engine.dense_wt.cpu()
+    assert ((wa - wb).abs() > 2e-5 + 1e-3 * wb.abs()).float().mean() < 1e-5 and (wa - wb).abs().max() <= 3 * 1.1e-5
     model.save_weights(str(tmp_path / 'trained.npz'))
     m2 = Model(inputs=inputs, outputs=outputs, seed=99)
     m2.load_weights(str(tmp_path / 'trained.npz'))

@@ -281,18 +281,31 @@ class Model:
         yp = self.predict(x, batch_size=len(x), as_numpy=False)
         return float(ops.yolo_loss_fwd_bwd(self._to_device(y), yp, self.B, self.C, self.img_size, want_grad=False)[0].item())
 
+    LOOKAHEAD = 2      # batches of a generator that share one pass of the frozen backbone (engine.Trainer.steps)
+
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, validation_data=None, validation_steps=None,
                       callbacks=None, verbose=1, **kw):
-        """Minimal epoch loop over a Sequence-like generator (len(), [i] -> (X, y)); the Keras
-        callback machinery (ModelCheckpoint / EarlyStopping) is out of scope."""
+        """Minimal epoch loop over a Sequence-like generator (len(), [i] -> (X, y)), /root/reference/train.py:94-104; the
+        Keras callback machinery (ModelCheckpoint / EarlyStopping) is out of scope.
+        Consecutive batches of equal shape go through Trainer.steps LOOKAHEAD at a time (one pass of the frozen backbone,
+        then one optimisation step per batch, in order), the update stays in flight under the next pass, and the losses
+        stay on the device until the epoch ends: no host synchronisation per step."""
         history = {'loss': [], 'val_loss': []}
         steps = steps_per_epoch or len(generator)
+        t = self._get_trainer()
         for ep in range(epochs):
-            tot = 0.0
-            for i in range(steps):
-                X, y = generator[i]
-                tot += self.train_on_batch(X, y)
-            history['loss'].append(tot / steps)
+            losses, i = [], 0
+            while i < steps:
+                group = [generator[j] for j in range(i, min(i + self.LOOKAHEAD, steps))]
+                while len(group) > 1 and any(np.shape(g[0]) != np.shape(group[0][0]) for g in group):
+                    group.pop()                      # a ragged last batch takes its step alone
+                X = torch.cat([self._to_device(g[0]) for g in group]) if len(group) > 1 else self._to_device(group[0][0])
+                y = torch.cat([self._to_device(g[1]) for g in group]) if len(group) > 1 else self._to_device(group[0][1])
+                self._trained = True
+                losses.append(t.steps(X, y, X.shape[0] // len(group), wait=False))
+                i += len(group)
+            t.join()
+            history['loss'].append(float(torch.cat(losses).sum().item()) / steps)
             if validation_data is not None:
                 vs = validation_steps or len(validation_data)
                 history['val_loss'].append(sum(self.test_on_batch(*validation_data[i]) for i in range(vs)) / vs)
