@@ -553,6 +553,11 @@ def main():
     ap.add_argument('--force-gather', action='store_true',
                     help='developer check: run the N>1 code path (process group, detection gather, all-reduce) on one rank')
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON: what libraries write to fd 1 on the way (RCCL prints a five-line version banner when
+    # its first communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get('TY1_BENCH_TRACE'):               # developer aid: full collections of the cyclic collector, with their duration
         gc_t = {}
 
@@ -617,7 +622,7 @@ def main():
     if ctx.rank == 0:
         if ctx.world == 1 and not args.no_cpu_baseline and prm is not None:
             out['cpu_baseline'] = cpu_baseline(prm, x_cpu, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     ctx.close()
 
 
