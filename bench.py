@@ -7,13 +7,14 @@
 A "step" is one pass of the hot path over one batch of synthetic images already resident in HBM.
 The contract line (ONE JSON line on rank 0) is BASELINE.json configs[1]: batch 64 per GPU, fp32; for N > 1
 every rank runs the same per-GPU batch (weak scaling: the path shards by image with no data-path collective) and the
-fixed-size detection records are all-gathered inside the step.
+fixed-size detection records are all-gathered every step (asynchronously: the collective completes under the next step).
 
 The same line carries, under "also", the two BASELINE.json configs that are multi-GPU by definition, measured in the
 same process right after the headline (skip with --no-also):
   configs[2]  bf16 inference, 128 images per GPU (1024 over 8), detection gather inside the step when N > 1
   configs[3]  VOC-20 training step, 32 images per GPU: frozen backbone fwd + Dense + yolo_loss fwd/bwd + wgrad +
-              ONE SUM all-reduce (overlapped with the next batch's backbone) + Adam
+              ONE SUM all-reduce + Adam (everything behind the backbone on a side stream under the next backbone pass;
+              one pass per --train-group = 2 batches, the one-pass-per-batch figure beside it)
 Either can be made the headline instead: --mode infer --dtype bf16, or --mode train.
 """
 import argparse
@@ -321,27 +322,39 @@ def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
         xin = model.input_buffer(N)
         xin.copy_(x)
         x = xin
-    rec = gathered = None
+    recs = gathers = None
     if ctx.multi:
-        rec = torch.empty((N, 98, 6), dtype=torch.float64, device=ctx.dev)          # box(4) score cls*keep
-        gathered = torch.empty((ctx.world * N, 98, 6), dtype=torch.float64, device=ctx.dev)
-    state = {}
+        # two sets of buffers: the gather of step i runs on RCCL's stream while the compute stream is already in step i + 1
+        # (nothing in the next step needs the gathered records), so a rank neither waits for the collective's latency nor,
+        # step by step, for the slowest device of the group; step i + 2 waits for gather i before it refills the records
+        recs = [torch.empty((N, 98, 6), dtype=torch.float64, device=ctx.dev) for _ in range(2)]          # box(4) score cls*keep
+        gathers = [torch.empty((ctx.world * N, 98, 6), dtype=torch.float64, device=ctx.dev) for _ in range(2)]
+    state = {'i': 0, 'work': [None, None]}
 
     def step():
         boxes, score, cls, keep = model.detect_replay(x) if args.graph else model.detect(x)
         if ctx.multi:                                  # detection gather: fixed-size records, one collective
-            ops.pack_detections(boxes, score, cls, keep, out=rec)
+            b = state['i'] & 1
+            state['i'] += 1
+            if state['work'][b] is not None:
+                state['work'][b].wait()                # stream-ordered: the compute stream waits for the gather of two steps ago
+            ops.pack_detections(boxes, score, cls, keep, out=recs[b])
             if ctx.backend == 'nccl':
-                ctx.dist.all_gather_into_tensor(gathered, rec)
+                state['work'][b] = ctx.dist.all_gather_into_tensor(gathers[b], recs[b], async_op=True)
             else:                                      # rehearsal backend: staged through the host
-                host = torch.empty(gathered.shape, dtype=gathered.dtype)
-                ctx.dist.all_gather_into_tensor(host, rec.cpu())
-                gathered.copy_(host)
+                host = torch.empty(gathers[b].shape, dtype=gathers[b].dtype)
+                ctx.dist.all_gather_into_tensor(host, recs[b].cpu())
+                gathers[b].copy_(host)
+            state['gathered'] = gathers[b]
         state['keep'] = keep
 
     est = 1.65 if dtype == 'f32' else 0.8
     m = measure(ctx, step, args, dtype, 'infer', est * N / (64 if dtype == 'f32' else 128), detailed)
+    for w in state['work']:
+        if w is not None:
+            w.wait()
     kept = float(state['keep'].sum().item()) / N
+    gathered = state.get('gathered')
     K, world = args.steps, ctx.world
     res = {
         'value': round(world * N * K / m['elapsed'], 1), 'unit': 'images/sec',
@@ -354,7 +367,7 @@ def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
                                  'NMS stress), torch.rand images resident in HBM',
                    'global_batch': world * N, 'per_gpu_batch': N,
                    'sharding': 'batch split across ranks, no data-path collective'
-                               + ('; all-gather of fixed-size detection records inside the step' if ctx.multi else ''),
+                               + ('; all-gather of fixed-size detection records every step, in flight under the next step' if ctx.multi else ''),
                    'kept_boxes_per_image': round(kept, 2)},
         'repeat_without_events_images_per_sec': round(world * N * K / m['plain'], 1),
         'cold_start_images_per_sec': round(world * N * K / m['cold'], 1),
