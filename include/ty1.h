@@ -297,6 +297,9 @@ int ty1_get_reserved_cus(int *k);
 int ty1_prof_enable(int on);
 /* Restrict the event brackets to launches whose name starts with `prefix` (NULL or "": all launches). */
 int ty1_prof_filter(const char *prefix);
+/* Bracket only every n-th launch that passes the filter (n <= 1: every one).  Two event records per launch cost the stream a
+ * few microseconds; a sample of the launches gives the same average duration at a fraction of that. */
+int ty1_prof_stride(int n);
 int ty1_prof_reset(void);
 int ty1_prof_query(const char *prefix, int *launches, double *total_ms);
 /* Writes up to cap bytes of "name launches total_ms\n" lines for every kernel seen. */

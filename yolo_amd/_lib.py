@@ -44,6 +44,7 @@ SIGNATURES = {
     'ty1_prof_enable': [_i],
     'ty1_prof_reset': [],
     'ty1_prof_filter': [_c.c_char_p],
+    'ty1_prof_stride': [_i],
     'ty1_prof_query': [_c.c_char_p, _c.POINTER(_i), _c.POINTER(_d)],
     'ty1_prof_dump': [_c.c_char_p, _c.c_size_t],
     'ty1_debug_stamp_buffer': [_vp, _i64],

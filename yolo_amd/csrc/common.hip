@@ -51,6 +51,7 @@ struct ProfEntry {
 };
 static thread_local bool g_prof_on = false;
 static thread_local std::string g_prof_filter;              // non-empty: only launches whose name starts with it
+static thread_local int g_prof_stride = 1, g_prof_seq = 0;     // bracket every g_prof_stride-th launch that passes the filter
 static thread_local std::map<std::string, ProfEntry> g_prof;
 static thread_local std::vector<hipEvent_t> g_event_pool;   // events are reused: creating two per launch is slow
 
@@ -68,6 +69,10 @@ ProfScope::ProfScope(const char *n, hipStream_t s, double fl, double by)
     : name(n), stream(s), flops(fl), bytes(by), on(g_prof_on) {
     if (!on) return;
     if (!g_prof_filter.empty() && name.compare(0, g_prof_filter.size(), g_prof_filter) != 0) {
+        on = false;
+        return;
+    }
+    if (g_prof_stride > 1 && (g_prof_seq++ % g_prof_stride) != 0) {
         on = false;
         return;
     }
@@ -142,6 +147,12 @@ int ty1_prof_enable(int on) {
 
 int ty1_prof_filter(const char *prefix) {
     ty1::g_prof_filter = prefix ? prefix : "";
+    return 0;
+}
+
+int ty1_prof_stride(int n) {
+    ty1::g_prof_stride = n > 1 ? n : 1;
+    ty1::g_prof_seq = 0;
     return 0;
 }
 

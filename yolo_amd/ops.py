@@ -449,20 +449,22 @@ def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7):
 class KernelTimer:
     """HIP-event timing of every library launch on its own stream (bench.py roofline leg)."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         """only: time just the launches whose name starts with this prefix (two event records per launch cost a few
-        per cent of a step when every launch is bracketed)."""
-        self.only = only
+        per cent of a step when every launch is bracketed); every: of those, only every n-th one."""
+        self.only, self.every = only, int(every)
 
     def __enter__(self):
         _lib.call('ty1_prof_reset')
         _lib.call('ty1_prof_filter', self.only.encode() if self.only else b'')
+        _lib.call('ty1_prof_stride', self.every)
         _lib.call('ty1_prof_enable', 1)
         return self
 
     def __exit__(self, *exc):
         _lib.call('ty1_prof_enable', 0)
         _lib.call('ty1_prof_filter', b'')
+        _lib.call('ty1_prof_stride', 1)
 
     @staticmethod
     def table():
