@@ -470,7 +470,7 @@ def run_train(ctx, args, N, detailed=True):
         no_coll = timed(ctx, step, K)
         tr.skip_collective = False
         one_per_batch = None
-        if G > 1:                      # the same K steps with one backbone pass per batch (Trainer.step), for comparison
+        if G > 1 and not args.no_train_compare:   # the same K steps with one backbone pass per batch (Trainer.step), for comparison
             x1, y1 = x[:N], yd[:N]
             step1 = lambda: tr.step(x1, y1, wait=False)
             for _ in range(10):
@@ -567,6 +567,8 @@ def main():
                     help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')
     ap.add_argument('--train-group', type=int, default=2,
                     help='training: consecutive batches that share one pass of the frozen backbone (Trainer.steps); 1 = Trainer.step per batch')
+    ap.add_argument('--no-train-compare', action='store_true',
+                    help='training: leave out the one-backbone-pass-per-batch comparison (profiling runs: it launches the same kernels at another size)')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')
     ap.add_argument('--settle-ms', type=float, default=200.0, help='untimed steps after the warm-up until the clocks have settled')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],

@@ -4,4 +4,4 @@ set -e
 TAG=${TAG:-r02h}
 TAG=$TAG bash tools/profile.sh
 TAG=${TAG}_bf16 MODE="--dtype bf16" SUFFIX=_bf16 bash tools/profile.sh
-TAG=${TAG}_train MODE="--mode train" SUFFIX=_train bash tools/profile.sh
+TAG=${TAG}_train MODE="--mode train --no-train-compare" SUFFIX=_train bash tools/profile.sh
