@@ -395,6 +395,56 @@ def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
     return res, prm, x_cpu
 
 
+def run_from_host(ctx, args, N, H0=480, W0=640):
+    """configs[1] fed from HOST memory: uint8 camera-sized frames in pinned buffers -> H2D on a copy stream (two device
+    buffers: the copy of batch i + 1 runs under the network of batch i) -> ty1_preprocess_batch_u8 (resize + /255, one launch)
+    -> detect.  The PCIe-inclusive rate of the path; never the headline `value`."""
+    from yolo_amd import ops, params as P
+    from yolo_amd.engine import DeviceModel
+    prm = P.make_random_params(seed=1, C=20, dense_init='glorot', bn='identity')
+    model = DeviceModel(prm, C=20, device=ctx.dev, dtype='f32')
+    gen = torch.Generator().manual_seed(7 + ctx.rank)
+    host = [torch.randint(0, 256, (N, H0, W0, 3), dtype=torch.uint8, generator=gen).pin_memory() for _ in range(2)]
+    dev_u8 = [torch.empty((N, H0, W0, 3), dtype=torch.uint8, device=ctx.dev) for _ in range(2)]
+    copy = torch.cuda.Stream(ctx.dev)
+    ready, free = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
+    state = {'i': 0}
+
+    def step():
+        b = state['i'] & 1
+        state['i'] += 1
+        cur = torch.cuda.current_stream(ctx.dev)
+        with torch.cuda.stream(copy):
+            copy.wait_event(free[b])                    # the preprocess of two steps ago has read this buffer
+            dev_u8[b].copy_(host[b], non_blocking=True)
+            ready[b].record(copy)
+        cur.wait_event(ready[b])
+        x = ops.preprocess_batch_u8(dev_u8[b], (model.img_size, model.img_size), out=model.input_buffer(N))    # = DeviceModel.detect_u8,
+        free[b].record(cur)                                                                                   # with the buffer handed back in between
+        state['keep'] = model.detect(x)[3]
+
+    nbytes = N * H0 * W0 * 3
+    ctx.sync()                                          # the link alone: what the pinned-buffer copy sustains with the GPU idle
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dev_u8[0].copy_(host[0], non_blocking=True)
+    ctx.sync()
+    link = 10 * nbytes / (time.perf_counter() - t0) / 1e9
+    for _ in range(args.warmup):
+        step()
+    settle(ctx, step, args.settle_ms, 1.7 * N / 64)
+    K = args.steps
+    el = timed(ctx, step, K)
+    return {'value': round(ctx.world * N * K / el, 1), 'unit': 'images/sec', 'ms_per_step': round(1e3 * el / K, 4), 'dtype': 'f32',
+            'config': {'workload': f'configs[1] from host memory: batch={N}/GPU of uint8 {H0}x{W0}x3 frames in pinned host buffers -> H2D on a '
+                                   'copy stream (double-buffered) -> resize to 448x448 + /255 on the GPU (one launch) -> backbone+Dense+head+'
+                                   'decode+NMS', 'per_gpu_batch': N},
+            'h2d_bytes_per_step': nbytes, 'h2d_GBps_sustained': round(nbytes * K / el / 1e9, 1), 'h2d_GBps_link_alone': round(link, 1),
+            'kept_boxes_per_image': round(float(state['keep'].sum().item()) / N, 2),
+            'note': 'PCIe-inclusive rate, never the headline value; h2d_GBps_link_alone = the same pinned copy with the GPU idle; the same batch as '
+                    'fp32 images (2.41 MB each) would need 2.6x these bytes'}
+
+
 def make_labels(N, C, seed):
     """SURVEY 8d training labels: 3 objects per image, uniform cell and class, first writer wins (data_sequence.py:79-85)."""
     rng = np.random.default_rng(seed)
@@ -628,8 +678,9 @@ def main():
 
         legs = [('configs[2] bf16 inference', sub, lambda: run_infer(ctx, sub, 'bf16', 128)[0]),
                 ('configs[3] training step', sub, lambda: run_train(ctx, sub, 32))]
-        if ctx.world == 1:                         # a single-GPU configuration: kept out of the N > 1 scaling runs
+        if ctx.world == 1:                         # single-GPU extras: kept out of the N > 1 scaling runs
             legs.append(('configs[4] single-class batch 4096', big, config4))
+            legs.append(('configs[1] from pinned host frames', sub, lambda: run_from_host(ctx, sub, 64)))
         for key, leg_args, fn in legs:
             if ctx.multi and ctx.backend != 'nccl' and 'training' in key:
                 # two ranks time-slicing ONE card: the compute stream of one rank stops inside the step's kernels while the

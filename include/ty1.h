@@ -125,6 +125,14 @@ int ty1_cast_f32_to_bf16(const float *x, void *y, long long n, ty1_stream_t stre
  */
 int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int swap_rb, float *out, int out_h, int out_w,
                       ty1_stream_t stream);
+/*
+ * The same for a batch of n equal-sized frames in one launch: imgs (n,H0,W0,3) uint8 -> out (n,out_h,out_w,3) fp32, frame by
+ * frame the arithmetic (and the bits) of ty1_preprocess_u8.  Replaces utils.py:11-15 applied over the batch loop of
+ * /root/reference/data_sequence.py:94-99 (for dataset in batch_datasets: ... X = np.array(images)) and the per-frame calls of
+ * a camera loop, where every frame has the camera's size.
+ */
+int ty1_preprocess_batch_u8(const unsigned char *imgs, int n, int H0, int W0, int swap_rb, float *out, int out_h, int out_w,
+                            ty1_stream_t stream);
 
 /*
  * Split-K Dense: part[s][n][u] = sum_{k in slice s} x[n][k] * wt[u][k]      (no bias here)

@@ -491,6 +491,30 @@ def test_preprocess_u8_vs_oracle(h0, w0):
     assert not batch[0].any() and not batch[2].any()
 
 
+@pytest.mark.parametrize('n,h0,w0', [(5, 480, 640), (3, 448, 448), (2, 896, 896), (1, 37, 1000)])
+def test_preprocess_batch_u8_equals_per_frame(n, h0, w0):
+    """ty1_preprocess_batch_u8 (equal-sized frames, one launch) = ty1_preprocess_u8 frame by frame = the checker's
+    restatement, bit for bit, with and without the channel swap; DeviceModel.detect_u8 = preprocess + detect."""
+    from oracle.resize_ref import load_img_ref
+    imgs = np.random.default_rng(n * h0 + w0).integers(0, 256, (n, h0, w0, 3), dtype=np.uint8)
+    d = torch.from_numpy(imgs).to(DEV)
+    for swap in (False, True):
+        got = ops.preprocess_batch_u8(d, (448, 448), swap_rb=swap)
+        for i in range(n):
+            assert torch.equal(got[i], ops.preprocess_u8(d[i], (448, 448), swap_rb=swap))
+        want = load_img_ref(imgs[0], (448, 448, 3)).astype(np.float32)
+        assert np.array_equal(got[0].cpu().numpy(), want[..., ::-1] if swap else want)
+    out = torch.zeros((n, 448, 448, 3), device=DEV)
+    assert ops.preprocess_batch_u8(d, (448, 448), out=out) is out
+    with pytest.raises(ValueError):
+        ops.preprocess_batch_u8(d[0])
+    if n == 5:
+        model = DeviceModel(P.make_random_params(seed=3, dense_init='spread', bn='random'), device=DEV)
+        a = [t.clone() for t in model.detect_u8(d)]
+        b = model.detect(ops.preprocess_batch_u8(d, (448, 448)))
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_detect_from_file_uses_device_preprocessing(tmp_path):
     """Regression check between the two product paths (file -> GPU preprocessing, host load_img -> upload)."""
     from PIL import Image

@@ -24,6 +24,7 @@ SIGNATURES = {
     'ty1_conv3x3_x2_c3_bf16': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
     'ty1_cast_f32_to_bf16': [_vp, _vp, _i64, _vp],
     'ty1_preprocess_u8': [_vp, _i, _i, _i, _vp, _i, _i, _vp],
+    'ty1_preprocess_batch_u8': [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
     'ty1_dense_splitk_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_dense_splitk_bf16': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     'ty1_head_activate_f32': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

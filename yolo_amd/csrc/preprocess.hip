@@ -34,8 +34,15 @@ __device__ __forceinline__ Tap tap_of(int o, int n_out, int n_in, bool x_axis) {
 // one thread per output pixel (3 channels): HBM-bound, 12 source bytes in and 12 bytes out per thread
 __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char *__restrict__ img, int H0, int W0, int swap_rb,
                                                            float *__restrict__ out, int OH, int OW) {
+    // uchar -> image / 255. in float64 -> Keras' cast to fp32: 256 possible results, computed once per workgroup with that very
+    // expression (a float64 division per channel and pixel was half of this kernel's time)
+    __shared__ float unit[256];
+    unit[threadIdx.x] = (float)((double)threadIdx.x / 255.0);
+    __syncthreads();
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= OH * OW) return;
+    img += (size_t)blockIdx.y * H0 * W0 * 3;               // blockIdx.y = frame of a batch of equal-sized frames
+    out += (size_t)blockIdx.y * OH * OW * 3;
     const int oy = idx / OW, ox = idx - oy * OW;
     const bool area2 = H0 == 2 * OH && W0 == 2 * OW;
     Tap ty, tx;
@@ -58,11 +65,25 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char 
             const int a = (p00 * tx.w0 + p01 * tx.w1) >> 4, b = (p10 * tx.w0 + p11 * tx.w1) >> 4;
             v = (((ty.w0 * a) >> 16) + ((ty.w1 * b) >> 16) + 2) >> 2;
         }
-        out[(size_t)idx * 3 + c] = (float)((double)(v & 255) / 255.0);      // uchar(...), image / 255. in float64, Keras' cast to fp32
+        out[(size_t)idx * 3 + c] = unit[v & 255];
     }
 }
 
 }  // namespace
+
+extern "C" int ty1_preprocess_batch_u8(const unsigned char *imgs, int n, int H0, int W0, int swap_rb, float *out, int out_h,
+                                       int out_w, ty1_stream_t stream) {
+    TY1_REQUIRE(n >= 0 && n <= 65535, "ty1_preprocess_batch_u8: n=%d not in 0..65535", n);
+    TY1_REQUIRE(H0 > 0 && W0 > 0 && out_h > 0 && out_w > 0, "ty1_preprocess_batch_u8: bad dimensions");
+    if (n == 0) return 0;
+    TY1_REQUIRE(imgs && out, "ty1_preprocess_batch_u8: null pointer");
+    TY1_REQUIRE((long long)out_h * out_w < (1ll << 31) && (long long)H0 * W0 * 3 < (1ll << 40), "ty1_preprocess_batch_u8: image too large");
+    hipStream_t s = (hipStream_t)stream;
+    ty1::ProfScope prof("preprocess_batch_u8", s, 0.0, (double)n * (12.0 * out_h * out_w + 3.0 * H0 * W0));
+    preprocess_u8_kernel<<<dim3((unsigned)(((long long)out_h * out_w + 255) / 256), (unsigned)n), 256, 0, s>>>(imgs, H0, W0, swap_rb, out,
+                                                                                                            out_h, out_w);
+    return ty1::check_launch("ty1_preprocess_batch_u8");
+}
 
 extern "C" int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int swap_rb, float *out, int out_h, int out_w,
                                  ty1_stream_t stream) {

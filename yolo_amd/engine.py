@@ -127,6 +127,14 @@ class DeviceModel:
                                    y=ws['y'] if want_y else None, out=ws['det'])
 
 
+    def detect_u8(self, frames_u8, swap_rb=False, iou_thr=0.2):
+        """Equal-sized uint8 frames (n,H0,W0,3) on the device -> detect(): cv2.resize + [BGR->RGB] + /255 of the whole batch
+        in one launch (ty1_preprocess_batch_u8; /root/reference/utils.py:11-15 over the batch loop of
+        data_sequence.py:94-99) into the batch's input buffer, then the network.  uint8 frames are a quarter of the fp32
+        batch on the PCIe link: from host frames a 64-image step stays compute-bound (bench.py, "from_host_frames")."""
+        x = ops.preprocess_batch_u8(frames_u8, (self.img_size, self.img_size), swap_rb, out=self.input_buffer(frames_u8.shape[0]))
+        return self.detect(x, iou_thr)
+
     # ------------------------------------------------------------------ one HIP-graph launch per batch
     def detect_replay(self, x, iou_thr=0.2):
         """detect() replayed as ONE HIP graph: the fixed launch sequence of a batch size (8 conv blocks, fix-ups, Dense,

@@ -191,6 +191,20 @@ def preprocess_u8(img_u8, out_hw=(448, 448), swap_rb=False, out=None):
     return out
 
 
+def preprocess_batch_u8(imgs_u8, out_hw=(448, 448), swap_rb=False, out=None):
+    """uint8 (n,H0,W0,3) equal-sized frames on the device -> fp32 (n,out_h,out_w,3) in [0,1] in ONE launch; frame by frame
+    the bits of preprocess_u8 (utils.py:11-15 over the batch loop of data_sequence.py:94-99, or over a camera's frames)."""
+    _chk(imgs_u8, torch.uint8, 'imgs')
+    if imgs_u8.dim() != 4 or imgs_u8.shape[3] != 3:
+        raise ValueError(f'imgs: expected (n,H0,W0,3) uint8, got {tuple(imgs_u8.shape)}')
+    n, H0, W0, _ = imgs_u8.shape
+    shape = (n, out_hw[0], out_hw[1], 3)
+    out = torch.empty(shape, dtype=torch.float32, device=imgs_u8.device) if out is None else _chk_out(out, torch.float32, shape, 'out')
+    _lib.call('ty1_preprocess_batch_u8', imgs_u8.data_ptr(), n, H0, W0, int(bool(swap_rb)), out.data_ptr(), out_hw[0], out_hw[1],
+              _lib.current_stream())
+    return out
+
+
 def pick_splits(K, n_rows, units, slots=None, chunk=DENSE_K_ALIGN):
     """Split-K factor for the Dense GEMM: the number of blocks (tiles * splits) that best fills ONE round of `slots`
     resident blocks, with at least 4 chunks (32 floats / 64 bf16 of K) per slice.  slots: 2 per CU for the 64 x 64 tiles
