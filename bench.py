@@ -445,6 +445,19 @@ def run_from_host(ctx, args, N, H0=480, W0=640):
                     'fp32 images (2.41 MB each) would need 2.6x these bytes'}
 
 
+def every_nth(n, fn):
+    """-> a step function that calls fn() on every n-th call.  fn() stands for n bench steps (Trainer.steps: n optimisation
+    steps behind one backbone pass), so ANY window of K consecutive calls, K a multiple of n, holds exactly K of them -
+    whatever the phase the window starts in."""
+    state = {'calls': 0}
+
+    def step():
+        state['calls'] += 1
+        if state['calls'] % n == 0:
+            fn()
+    return step
+
+
 def make_labels(N, C, seed):
     """SURVEY 8d training labels: 3 objects per image, uniform cell and class, first writer wins (data_sequence.py:79-85)."""
     rng = np.random.default_rng(seed)
@@ -490,10 +503,12 @@ def run_train(ctx, args, N, detailed=True):
                       f'updated={tr._updated.query()} pending={tr._pending} adam_deferred={tr._adam_deferred}', file=sys.stderr, flush=True)
         threading.Thread(target=probe, daemon=True).start()
 
+    def group():
+        state['loss'] = tr.steps(x, yd, N, wait=False)[-1:]         # tail, exchange + Adam stay in flight under the next backbone
+    grouped = every_nth(G, group)
+
     def step():
-        state['calls'] = state.get('calls', 0) + 1
-        if state['calls'] % G == 0:
-            state['loss'] = tr.steps(x, yd, N, wait=False)[-1:]     # tail, exchange + Adam stay in flight under the next backbone
+        grouped()
         if trace:
             state['i'] = state.get('i', 0) + 1
             print(f'[rank {ctx.rank}] train step {state["i"]} done at {time.perf_counter() - t_start:.3f} s', file=sys.stderr, flush=True)
