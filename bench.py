@@ -398,30 +398,20 @@ def run_infer(ctx, args, dtype, N, detailed=True, C=20, images_on_device=False):
 def run_from_host(ctx, args, N, H0=480, W0=640):
     """configs[1] fed from HOST memory: uint8 camera-sized frames in pinned buffers -> H2D on a copy stream (two device
     buffers: the copy of batch i + 1 runs under the network of batch i) -> ty1_preprocess_batch_u8 (resize + /255, one launch)
-    -> detect.  The PCIe-inclusive rate of the path; never the headline `value`."""
-    from yolo_amd import ops, params as P
-    from yolo_amd.engine import DeviceModel
+    -> detect (engine.HostFramePipeline).  The PCIe-inclusive rate of the path; never the headline `value`."""
+    from yolo_amd import params as P
+    from yolo_amd.engine import DeviceModel, HostFramePipeline
     prm = P.make_random_params(seed=1, C=20, dense_init='glorot', bn='identity')
     model = DeviceModel(prm, C=20, device=ctx.dev, dtype='f32')
     gen = torch.Generator().manual_seed(7 + ctx.rank)
     host = [torch.randint(0, 256, (N, H0, W0, 3), dtype=torch.uint8, generator=gen).pin_memory() for _ in range(2)]
-    dev_u8 = [torch.empty((N, H0, W0, 3), dtype=torch.uint8, device=ctx.dev) for _ in range(2)]
-    copy = torch.cuda.Stream(ctx.dev)
-    ready, free = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
+    pipe = HostFramePipeline(model, N, H0, W0)
+    dev_u8 = pipe.frames
     state = {'i': 0}
 
     def step():
-        b = state['i'] & 1
         state['i'] += 1
-        cur = torch.cuda.current_stream(ctx.dev)
-        with torch.cuda.stream(copy):
-            copy.wait_event(free[b])                    # the preprocess of two steps ago has read this buffer
-            dev_u8[b].copy_(host[b], non_blocking=True)
-            ready[b].record(copy)
-        cur.wait_event(ready[b])
-        x = ops.preprocess_batch_u8(dev_u8[b], (model.img_size, model.img_size), out=model.input_buffer(N))    # = DeviceModel.detect_u8,
-        free[b].record(cur)                                                                                   # with the buffer handed back in between
-        state['keep'] = model.detect(x)[3]
+        state['keep'] = pipe.submit(host[state['i'] & 1])[3]
 
     nbytes = N * H0 * W0 * 3
     ctx.sync()                                          # the link alone: what the pinned-buffer copy sustains with the GPU idle
@@ -435,7 +425,17 @@ def run_from_host(ctx, args, N, H0=480, W0=640):
     settle(ctx, step, args.settle_ms, 1.7 * N / 64)
     K = args.steps
     el = timed(ctx, step, K)
+    # a second pass with one event per step: the spread of the step time on the GPU's own clock
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+    ctx.sync()
+    marks[0].record()
+    for i in range(K):
+        step()
+        marks[i + 1].record()
+    ctx.sync()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(K))
     return {'value': round(ctx.world * N * K / el, 1), 'unit': 'images/sec', 'ms_per_step': round(1e3 * el / K, 4), 'dtype': 'f32',
+            'step_ms_p10_p50_p90_max': [round(per_step[K // 10], 3), round(per_step[K // 2], 3), round(per_step[(9 * K) // 10], 3), round(per_step[-1], 3)],
             'config': {'workload': f'configs[1] from host memory: batch={N}/GPU of uint8 {H0}x{W0}x3 frames in pinned host buffers -> H2D on a '
                                    'copy stream (double-buffered) -> resize to 448x448 + /255 on the GPU (one launch) -> backbone+Dense+head+'
                                    'decode+NMS', 'per_gpu_batch': N},

@@ -174,6 +174,42 @@ class DeviceModel:
         return buf
 
 
+class HostFramePipeline:
+    """Detection from frames in HOST memory (the per-frame loop of /root/reference/tiny_yolov1.py:142-160 and the batch loop of
+    data_sequence.py:94-99, fed the way a server is: frames arrive in host buffers).  submit(frames) copies one batch of
+    equal-sized uint8 frames (n,H0,W0,3) - pinned host memory for an asynchronous copy - to one of two device buffers on a
+    copy stream, so the copy of batch i + 1 runs under the network of batch i, then resizes the whole batch in one launch
+    (ty1_preprocess_batch_u8) and runs detect().  uint8 frames are a quarter of the fp32 batch on the link.
+    The host stays at most two batches ahead: submit() waits (on the host) for the device buffer it is about to overwrite -
+    left to run fifty batches ahead, hipMemcpyAsync blocks at times while the pipeline is still empty."""
+
+    def __init__(self, model, n, H0, W0, swap_rb=False, iou_thr=0.2):
+        self.model, self.n, self.swap_rb, self.iou_thr = model, n, swap_rb, iou_thr
+        dev = model.device
+        self.frames = [torch.empty((n, H0, W0, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.copy = torch.cuda.Stream(dev)
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.i = 0
+
+    def submit(self, frames_u8_host):
+        """-> detect()'s (boxes, score, cls, keep) for this batch, on the device; valid until the next submit()."""
+        if tuple(frames_u8_host.shape) != tuple(self.frames[0].shape) or frames_u8_host.dtype != torch.uint8:
+            raise ValueError(f'frames: expected uint8 {tuple(self.frames[0].shape)}, got {frames_u8_host.dtype} {tuple(frames_u8_host.shape)}')
+        m, b = self.model, self.i & 1
+        if self.i >= 2:
+            self.free[b].synchronize()               # the preprocess of two batches ago has read this buffer
+        self.i += 1
+        cur = torch.cuda.current_stream(m.device)
+        with torch.cuda.stream(self.copy):
+            self.frames[b].copy_(frames_u8_host, non_blocking=True)
+            self.ready[b].record(self.copy)
+        cur.wait_event(self.ready[b])
+        x = ops.preprocess_batch_u8(self.frames[b], (m.img_size, m.img_size), self.swap_rb, out=m.input_buffer(self.n))
+        self.free[b].record(cur)
+        return m.detect(x, self.iou_thr)
+
+
 class Trainer:
     """One training step of the reference's configuration (train.py:59-60): the frozen
     backbone and the Dense layer run forward, yolo_loss gives dL/dy_pred in closed form, the head
