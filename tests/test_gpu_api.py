@@ -489,6 +489,8 @@ def test_preprocess_u8_vs_oracle(h0, w0):
     ops.preprocess_u8(d, (224, 224), out=batch[1])
     assert np.array_equal(batch[1].cpu().numpy(), (resize_linear_u8_ref(img, 224, 224) / 255.).astype(np.float32))
     assert not batch[0].any() and not batch[2].any()
+    # a tiny odd output size
+    assert np.array_equal(ops.preprocess_u8(d, (9, 9)).cpu().numpy(), (resize_linear_u8_ref(img, 9, 9) / 255.).astype(np.float32))
 
 
 @pytest.mark.parametrize('n,h0,w0', [(5, 480, 640), (3, 448, 448), (2, 896, 896), (1, 37, 1000)])
