@@ -530,7 +530,7 @@ def test_host_frame_pipeline_equals_detect_u8():
     pipe = HostFramePipeline(model, n, H0, W0)
     pinned = [torch.empty((n, H0, W0, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
     for i, b in enumerate(batches):
-        pinned[i & 1].copy_(b)                       # (this host buffer was submitted two batches ago: its copy is done)
+        pinned[i & 1].copy_(b)                       # (submitted two batches ago; the submit() after that has returned: it is free)
         got = pipe.submit(pinned[i & 1])
         assert all(torch.equal(x, y) for x, y in zip(got, want[i])), i
     with pytest.raises(ValueError):

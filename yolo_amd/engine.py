@@ -181,7 +181,9 @@ class HostFramePipeline:
     copy stream, so the copy of batch i + 1 runs under the network of batch i, then resizes the whole batch in one launch
     (ty1_preprocess_batch_u8) and runs detect().  uint8 frames are a quarter of the fp32 batch on the link.
     The host stays at most two batches ahead: submit() waits (on the host) for the device buffer it is about to overwrite -
-    left to run fifty batches ahead, hipMemcpyAsync blocks at times while the pipeline is still empty."""
+    left to run fifty batches ahead, hipMemcpyAsync blocks at times while the pipeline is still empty - and for the copy of
+    the PREVIOUS batch: when submit() returns, that batch's host buffer may be refilled (two host buffers, used in turn,
+    are enough)."""
 
     def __init__(self, model, n, H0, W0, swap_rb=False, iou_thr=0.2):
         self.model, self.n, self.swap_rb, self.iou_thr = model, n, swap_rb, iou_thr
@@ -198,7 +200,9 @@ class HostFramePipeline:
             raise ValueError(f'frames: expected uint8 {tuple(self.frames[0].shape)}, got {frames_u8_host.dtype} {tuple(frames_u8_host.shape)}')
         m, b = self.model, self.i & 1
         if self.i >= 2:
-            self.free[b].synchronize()               # the preprocess of two batches ago has read this buffer
+            self.free[b].synchronize()               # the preprocess of two batches ago has read this device buffer
+        if self.i >= 1:
+            self.ready[b ^ 1].synchronize()          # the previous batch has left its host buffer
         self.i += 1
         cur = torch.cuda.current_stream(m.device)
         with torch.cuda.stream(self.copy):
@@ -224,7 +228,7 @@ class Trainer:
     and BatchNormalization layer is frozen (/root/reference/models/model_tiny_yolov1.py:43-87, trainable=False), so
     the backbone reads nothing the tail writes, and the side stream's order alone puts step i+1's Dense forward behind
     step i's update.  The only edge back: the next backbone's last layer overwrites the feature buffer, so the compute
-    stream waits (in the middle of that backbone, long after the fact) for the tail to have read it.  step(wait=True),
+    stream waits (right before that layer, long after the fact) for the tail to have read it.  step(wait=True),
     the default, ends with join(): loss and weights are then ordered on the caller's stream.  The arithmetic and its
     order are those of the serial step: same bits (tests/test_gpu_api.py)."""
 
