@@ -15,7 +15,9 @@ same process right after the headline (skip with --no-also):
   configs[3]  VOC-20 training step, 32 images per GPU: frozen backbone fwd + Dense + yolo_loss fwd/bwd + wgrad +
               ONE SUM all-reduce + Adam (everything behind the backbone on a side stream under the next backbone pass;
               one pass per --train-group = 2 batches, the one-pass-per-batch figure beside it)
-Either can be made the headline instead: --mode infer --dtype bf16, or --mode train.
+On one GPU two more legs follow: configs[4] (C = 1, 4096 images, whole network) and configs[1] fed from pinned HOST frames
+(uint8 480x640, copy stream + one-launch GPU resize: the PCIe-inclusive rate, never the headline value).
+Either of configs[2] / configs[3] can be made the headline instead: --mode infer --dtype bf16, or --mode train.
 """
 import argparse
 import gc
