@@ -20,8 +20,10 @@ namespace {
 struct Tap {
     int i0, i1, w0, w1;
 };
-__device__ __forceinline__ Tap tap_of(int o, int n_out, int n_in, bool x_axis) {
-    const float f = (float)(((double)o + 0.5) * ((double)n_in / (double)n_out) - 0.5);
+// ratio = (double)n_in / (double)n_out, divided once on the host (IEEE division: the same double as on the device): per
+// thread the float64 division was most of this kernel's arithmetic
+__device__ __forceinline__ Tap tap_of(int o, double ratio, int n_in, bool x_axis) {
+    const float f = (float)(((double)o + 0.5) * ratio - 0.5);
     const float fl = floorf(f);
     float frac = f - fl;
     const int s = (int)fl;
@@ -33,7 +35,7 @@ __device__ __forceinline__ Tap tap_of(int o, int n_out, int n_in, bool x_axis) {
 
 // one thread per output pixel (3 channels): HBM-bound, 12 source bytes in and 12 bytes out per thread
 __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char *__restrict__ img, int H0, int W0, int swap_rb,
-                                                           float *__restrict__ out, int OH, int OW) {
+                                                           float *__restrict__ out, int OH, int OW, double ry, double rx) {
     // uchar -> image / 255. in float64 -> Keras' cast to fp32: 256 possible results, computed once per workgroup with that very
     // expression (a float64 division per channel and pixel was half of this kernel's time)
     __shared__ float unit[256];
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char 
         ty = Tap{2 * oy, 2 * oy + 1, 0, 0};
         tx = Tap{2 * ox, 2 * ox + 1, 0, 0};
     } else {
-        ty = tap_of(oy, OH, H0, false);
-        tx = tap_of(ox, OW, W0, true);
+        ty = tap_of(oy, ry, H0, false);
+        tx = tap_of(ox, rx, W0, true);
     }
     const unsigned char *r0 = img + (size_t)ty.i0 * W0 * 3, *r1 = img + (size_t)ty.i1 * W0 * 3;
 #pragma unroll
@@ -81,7 +83,7 @@ extern "C" int ty1_preprocess_batch_u8(const unsigned char *imgs, int n, int H0,
     hipStream_t s = (hipStream_t)stream;
     ty1::ProfScope prof("preprocess_batch_u8", s, 0.0, (double)n * (12.0 * out_h * out_w + 3.0 * H0 * W0));
     preprocess_u8_kernel<<<dim3((unsigned)(((long long)out_h * out_w + 255) / 256), (unsigned)n), 256, 0, s>>>(imgs, H0, W0, swap_rb, out,
-                                                                                                            out_h, out_w);
+                                                                                                            out_h, out_w, (double)H0 / (double)out_h, (double)W0 / (double)out_w);
     return ty1::check_launch("ty1_preprocess_batch_u8");
 }
 
@@ -92,6 +94,7 @@ extern "C" int ty1_preprocess_u8(const unsigned char *img, int H0, int W0, int s
     TY1_REQUIRE((long long)out_h * out_w < (1ll << 31) && (long long)H0 * W0 * 3 < (1ll << 40), "ty1_preprocess_u8: image too large");
     hipStream_t s = (hipStream_t)stream;
     ty1::ProfScope prof("preprocess_u8", s, 0.0, 12.0 * out_h * out_w + 3.0 * H0 * W0);
-    preprocess_u8_kernel<<<(unsigned)(((long long)out_h * out_w + 255) / 256), 256, 0, s>>>(img, H0, W0, swap_rb, out, out_h, out_w);
+    preprocess_u8_kernel<<<(unsigned)(((long long)out_h * out_w + 255) / 256), 256, 0, s>>>(img, H0, W0, swap_rb, out, out_h, out_w, (double)H0 / (double)out_h,
+                                                                                            (double)W0 / (double)out_w);
     return ty1::check_launch("ty1_preprocess_u8");
 }
