@@ -517,13 +517,14 @@ def test_preprocess_batch_u8_equals_per_frame(n, h0, w0):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
-def test_host_frame_pipeline_equals_detect_u8():
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_host_frame_pipeline_equals_detect_u8(dtype):
     """engine.HostFramePipeline (pinned host frames -> copy stream -> one-launch resize -> detect, two device buffers) gives
     the detections of DeviceModel.detect_u8 on the same frames, batch after batch, also when the caller refills its host
     buffer right after submit() returns only once the NEXT submit has been made (the copy is asynchronous)."""
     from yolo_amd.engine import HostFramePipeline
     n, H0, W0 = 6, 240, 320
-    model = DeviceModel(P.make_random_params(seed=3, dense_init='spread', bn='random'), device=DEV)
+    model = DeviceModel(P.make_random_params(seed=3, dense_init='spread', bn='random'), device=DEV, dtype=dtype)
     rng = np.random.default_rng(17)
     batches = [torch.from_numpy(rng.integers(0, 256, (n, H0, W0, 3), dtype=np.uint8)) for _ in range(5)]
     want = [[t.clone() for t in model.detect_u8(b.to(DEV))] for b in batches]
