@@ -13,8 +13,10 @@ The same line carries, under "also", the two BASELINE.json configs that are mult
 same process right after the headline (skip with --no-also):
   configs[2]  bf16 inference, 128 images per GPU (1024 over 8), detection gather inside the step when N > 1
   configs[3]  VOC-20 training step, 32 images per GPU: frozen backbone fwd + Dense + yolo_loss fwd/bwd + wgrad +
-              ONE SUM all-reduce + Adam (everything behind the backbone on a side stream under the next backbone pass;
-              one pass per --train-group = 2 batches, the one-pass-per-batch figure beside it)
+              gradient exchange + Adam (everything behind the backbone on a side stream under the next backbone pass;
+              one pass per --train-group = 2 batches, the one-pass-per-batch figure beside it).  Exchange for N > 1:
+              --exchange gather (default: all-gather of features + dz, 1.8 MB per rank, every rank computes the group's
+              weight gradient) or allreduce (ONE SUM all-reduce of the 73.9 MB [dWt | db | loss] bucket)
 On one GPU two more legs follow: configs[4] (C = 1, 4096 images, whole network) and configs[1] fed from pinned HOST frames
 (uint8 480x640, copy stream + one-launch GPU resize: the PCIe-inclusive rate, never the headline value).
 Either of configs[2] / configs[3] can be made the headline instead: --mode infer --dtype bf16, or --mode train.
@@ -516,6 +518,7 @@ def run_train(ctx, args, N, detailed=True):
             print(f'[rank {ctx.rank}] train step {state["i"]} done at {time.perf_counter() - t_start:.3f} s', file=sys.stderr, flush=True)
 
     tr.bucket.always = ctx.multi                       # --force-gather: the collective runs on one rank too
+    tr.exchange = args.exchange                        # every rank of this bench has the same N: 'gather' is legal
     real_sync = ctx.sync
     ctx.sync = lambda: (tr.join(), real_sync())[1]
     try:
@@ -545,8 +548,23 @@ def run_train(ctx, args, N, detailed=True):
             one_per_batch = timed(ctx, step1, K)
     finally:
         ctx.sync = real_sync
-    nbytes = tr.bucket.nbytes()
     coll = statistics.median(coll_ms) if coll_ms else 0.0
+    active = world > 1 or ctx.multi
+    if args.exchange == 'gather':
+        nbytes = N * (12544 + tr.ldz) * 4
+        exch = {'kind': "all-gather of each rank's features (n x 12544) and dz (n x 1472, the loss in a padding column); every rank "
+                        "computes the group's weight gradient dz_all^T x_all itself (Trainer.exchange = 'gather')",
+                'collectives_per_step': 2 if active else 0, 'bytes_sent_per_rank_per_step': nbytes,
+                'bytes_received_per_rank_per_step': (world - 1) * nbytes,
+                'window_ms': round(coll, 4), 'window': 'both all-gathers with the Dense forward and the loss between them (device time)'}
+    else:
+        nbytes = tr.bucket.nbytes()
+        exch = {'kind': 'ONE SUM all-reduce of [dWt | db | loss] (Trainer.exchange = \'allreduce\')',
+                'collectives_per_step': 1 if active else 0, 'message_bytes': nbytes, 'device_ms': round(coll, 4),
+                'bus_GBps': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if coll > 0 and world > 1 else None}
+    exch.update({'ms_per_step_without_collective': round(1e3 * no_coll / K, 4),
+                 'exposed_ms': round(1e3 * (m['elapsed'] - no_coll) / K, 4),
+                 'share_of_step': round(max(0.0, (m['elapsed'] - no_coll) / m['elapsed']), 4)})
     res = {
         'value': round(world * N * K / m['elapsed'], 1), 'unit': 'images/sec',
         'steps_per_sec': round(K / m['elapsed'], 2),
@@ -558,15 +576,10 @@ def run_train(ctx, args, N, detailed=True):
                                   'then takes its own optimisation step (Trainer.steps)' if G > 1 else ''),
                    'global_batch': world * N, 'per_gpu_batch': N, 'batches_per_backbone_pass': G,
                    'sharding': 'batch split across ranks (data parallel), gradients summed (no division: the loss is a batch sum)',
-                   'overlap': 'all-reduce + Adam on a side stream under the next batch\'s frozen backbone'
+                   'overlap': 'Dense forward, loss, gradients, exchange and Adam on a side stream under the next frozen-backbone pass'
                               if not args.no_overlap else 'serial'},
         'loss': float(state['loss'].item()),
-        'allreduce': {'collectives_per_step': 1 if world > 1 or ctx.multi else 0, 'message_bytes': nbytes,
-                      'device_ms': round(coll, 4),
-                      'bus_GBps': round(2 * (world - 1) / world * nbytes / (coll * 1e-3) / 1e9, 1) if coll > 0 and world > 1 else None,
-                      'ms_per_step_without_collective': round(1e3 * no_coll / K, 4),
-                      'exposed_ms': round(1e3 * (m['elapsed'] - no_coll) / K, 4),
-                      'share_of_step': round(max(0.0, (m['elapsed'] - no_coll) / m['elapsed']), 4)},
+        'exchange': exch,
         'repeat_without_events_images_per_sec': round(world * N * K / m['plain'], 1),
         'cold_start_images_per_sec': round(world * N * K / m['cold'], 1),
         'whole_step_frac_of_mfma_peak': round(GFLOP_PER_IMAGE * 1e9 * N * K / m['elapsed'] / (PEAK_TFLOPS['f32'] * 1e12), 4),
@@ -634,6 +647,9 @@ def main():
                     help='training: hold the Adam launch back until the next backbone has enqueued this layer (-1: at once; default: the trainer\'s)')
     ap.add_argument('--train-group', type=int, default=2,
                     help='training: consecutive batches that share one pass of the frozen backbone (Trainer.steps); 1 = Trainer.step per batch')
+    ap.add_argument('--exchange', choices=['gather', 'allreduce'], default='gather',
+                    help='training, N > 1: all-gather features + dz and compute the group\'s weight gradient on every rank (1.8 MB per rank '
+                         'on the links), or ONE SUM all-reduce of the 73.9 MB gradient bucket')
     ap.add_argument('--no-train-compare', action='store_true',
                     help='training: leave out the one-backbone-pass-per-batch comparison (profiling runs: it launches the same kernels at another size)')
     ap.add_argument('--no-overlap', action='store_true', help='training: run the all-reduce + Adam serially on the compute stream')

@@ -388,22 +388,32 @@ def test_overlapped_step_equals_serial_step_one_rank_rccl():
             calls.append(t.numel())
             return real(t, *a, **k)
         results = {}
-        for mode in ('serial', 'overlap'):
+        gathers = []
+        real_gather = dist.all_gather_into_tensor
+
+        def counting_gather(out, inp, *a, **k):
+            gathers.append(tuple(inp.shape))
+            return real_gather(out, inp, *a, **k)
+        for mode in ('serial', 'overlap', 'gather'):
             model = DeviceModel(prm, device=DEV)
-            tr = Trainer(model, lr=1e-5, overlap=(mode == 'overlap'))
+            tr = Trainer(model, lr=1e-5, overlap=(mode != 'serial'))
             assert tr.bucket.flat.numel() == 1472 * 12544 + 1470 + 1
             tr.bucket.always = True          # a one-rank group would short-cut the collective: send it through RCCL
-            dist.all_reduce = counting
+            if mode == 'gather':             # features and dz travel instead of the weight gradient (Trainer.exchange)
+                tr.exchange = 'gather'
+            dist.all_reduce, dist.all_gather_into_tensor = counting, counting_gather
             try:
                 losses = [tr.step(x, y, wait=(mode == 'serial')) for x, y in zip(xs, ys)]
                 tr.join()
                 torch.cuda.synchronize()
             finally:
-                dist.all_reduce = real
+                dist.all_reduce, dist.all_gather_into_tensor = real, real_gather
             results[mode] = (torch.cat(losses).cpu(), model.dense_wt.clone().cpu(), model.dense_b.clone().cpu(), tr.m.clone().cpu())
-        assert calls == [1472 * 12544 + 1470 + 1] * 6                    # one message per step, both modes
-        for a, b in zip(results['serial'], results['overlap']):
-            assert torch.isfinite(a).all() and torch.equal(a, b)
+        assert calls == [1472 * 12544 + 1470 + 1] * 6                    # one message per step in the two all-reduce modes, none in 'gather'
+        assert gathers == [(N, 12544), (N, 1472)] * 3                    # ... which sends the features and dz of each step
+        for mode in ('overlap', 'gather'):                               # (one rank: the gathered rows ARE the local rows - same bits)
+            for a, b in zip(results['serial'], results[mode]):
+                assert torch.isfinite(a).all() and torch.equal(a, b), mode
         assert results['serial'][0][2] < results['serial'][0][0]          # it learns
     finally:
         dist.destroy_process_group()

@@ -3,7 +3,8 @@ single [dWt | db | loss] collective, the side-stream overlap) on the HIP kernels
 the collective travels over gloo here (it accepts device tensors); with RCCL the same code path is covered on one rank by
 test_gpu_api.py::test_overlapped_step_equals_serial_step_one_rank_rccl.  What is checked: the data-parallel step on ragged
 shards (5 + 3 images) gives the full batch's summed loss and gradient (SUM, no division: SURVEY Q12), and both ranks
-hold bit-identical weights afterwards."""
+hold bit-identical weights afterwards; the same for Trainer.exchange = 'gather' on equal shards (4 + 4), where features and
+dz travel instead of the weight gradient."""
 import os
 
 import numpy as np
@@ -62,7 +63,25 @@ def _worker(rank, world, port, q):
         ws = [torch.empty_like(w) for _ in range(world)] if rank == 0 else None
         dist.gather(w, ws, dst=0)
         ok_same = True if rank != 0 else bool(torch.equal(ws[0], ws[1]))
-        q.put((rank, ok_one, ok_loss, ok_grad, ok_same, bool(np.isfinite(loss2)), loss_dp.item(), loss_full))
+        # Trainer.exchange = 'gather': equal shards (4 + 4), features and dz all-gathered, every rank computes the group's
+        # weight gradient itself - no all-reduce; against the same whole-batch reference
+        lo, hi = [(0, 4), (4, 8)][rank]
+        model_g = DeviceModel(prm, device=dev)
+        tg = Trainer(model_g, lr=1e-5, overlap=True)
+        tg.exchange = 'gather'
+        calls.clear()
+        dist.all_reduce = counting
+        loss_g = tg.step(x[lo:hi].contiguous(), y[lo:hi].contiguous(), wait=False)
+        tg.join()
+        torch.cuda.synchronize()
+        dist.all_reduce = real
+        ok_gather = (not calls and abs(loss_g.item() - loss_full) <= 2e-4 * abs(loss_full)
+                     and (tg.bucket.grads - g_full).abs().max().item() <= 2e-3 * scale)
+        wg = tg.pflat.cpu()
+        wgs = [torch.empty_like(wg) for _ in range(world)] if rank == 0 else None
+        dist.gather(wg, wgs, dst=0)
+        ok_gather = ok_gather and (True if rank != 0 else bool(torch.equal(wgs[0], wgs[1])))
+        q.put((rank, ok_one, ok_loss, ok_grad, ok_same, bool(np.isfinite(loss2)), ok_gather, loss_dp.item(), loss_full))
     finally:
         dist.destroy_process_group()
 

@@ -10,7 +10,7 @@ for i in $(seq 1 $R); do
   python3 -c "
 import json,re
 d=json.load(open('gpurun_out/dstall_$i.json')); t=d['also']['configs[3] training step']
-print($i, 'no_freeze=${TY1_BENCH_NO_GC_FREEZE:-0}', d['value'], t['value'], t['repeat_without_events_images_per_sec'], t['allreduce']['exposed_ms'])
+print($i, 'no_freeze=${TY1_BENCH_NO_GC_FREEZE:-0}', d['value'], t['value'], t['repeat_without_events_images_per_sec'], t['exchange']['exposed_ms'])
 ts=[float(m.group(1)) for m in re.finditer(r'done at ([0-9.]+) s', open('gpurun_out/dstall_$i.err').read())]
 gaps=sorted(((b-a,k) for k,(a,b) in enumerate(zip(ts,ts[1:]))), reverse=True)[:4]
 print('  steps', len(ts), 'largest host gaps (s, after step):', [(round(g,4),k+1) for g,k in gaps])"

@@ -6,5 +6,5 @@ for i in $(seq 1 $R); do
   timeout -k 10 200 python bench.py --mode train --steps 50 --warmup 10 --no-cpu-baseline "$@" > gpurun_out/stall_$i.json 2> gpurun_out/stall_$i.err
   python3 -c "
 import json
-d=json.load(open('gpurun_out/stall_$i.json')); print($i, d['value'], d['repeat_without_events_images_per_sec'], d['cold_start_images_per_sec'], d['allreduce']['ms_per_step_without_collective'], d['roofline']['kernel'])"
+d=json.load(open('gpurun_out/stall_$i.json')); print($i, d['value'], d['repeat_without_events_images_per_sec'], d['cold_start_images_per_sec'], d['exchange']['ms_per_step_without_collective'], d['roofline']['kernel'])"
 done

@@ -264,6 +264,16 @@ class Trainer:
         self.collective_events = None    # (start, end) CUDA events around the last all-reduce when time_collective is set
         self.time_collective = False
         self.skip_collective = False     # measurement only (bench: step time without the exchange)
+        # How the ranks of a data-parallel group arrive at the same summed gradient:
+        #  'allreduce': each rank's dWt = dz^T x, then ONE SUM all-reduce of [dWt | db | loss] (73.9 MB); any shard sizes.
+        #  'gather':    all-gather of the features (n x 12544) and of dz (n x 1472, the local loss rides in a padding column),
+        #               then every rank computes the GLOBAL dWt = dz_all^T x_all itself: 1.8 MB per rank on the links instead
+        #               of 73.9 MB through a ring (xGMI is point to point: an all-reduce of that size is link-bound), for a
+        #               weight-gradient GEMM world-size times deeper (its 73.8 MB store bounds it up to ~4 ranks, then the
+        #               MFMAs: 60 us at 8).  Needs the same number of images on every rank.  Same sum, other order; every
+        #               rank runs the same kernel on the same gathered rows: bit-identical weights across ranks.
+        self.exchange = 'allreduce'
+        self._gathered = {}
         self.tail_on_side = True         # False: Dense forward / loss / weight gradient on the compute stream (same bits; A/B)
         self.fused_tail = True           # False: the three separate launches (same bits; kept for the comparison test)
         # step(wait=False) only: the Adam launch of the update in flight is held back until the NEXT batch's backbone has
@@ -290,23 +300,61 @@ class Trainer:
         self.join()
         return self._tail(feats, y_true)
 
+    def _gathers(self):
+        """True when this step exchanges features and dz instead of the weight gradient (self.exchange == 'gather' in a group
+        of more than one rank, or the one-rank rehearsal of it)."""
+        from . import parallel
+        return (self.exchange == 'gather' and not self.skip_collective and self.ldz > self.model.units
+                and (parallel.world(self.group)[1] > 1 or self.bucket.always))
+
     def _tail(self, feats, y_true):
-        """Dense forward, head + loss + head Jacobian, Dense weight gradient: enqueued on the CURRENT stream."""
+        """Dense forward, head + loss + head Jacobian, Dense weight gradient: enqueued on the CURRENT stream.  In 'gather'
+        mode the two all-gathers sit in between and the weight gradient is the group's (no all-reduce follows)."""
+        from . import parallel
         m = self.model
         N = feats.shape[0]
         ws = m.workspace(N)
         dz = self._dz.get(N)
         if dz is None:
             dz = self._dz[N] = torch.empty((N, self.ldz), dtype=torch.float32, device=self.device)
+        gathers = self._gathers()
+        works = []
+        if gathers:
+            W = parallel.world(self.group)[1]
+            bufs = self._gathered.get(N)
+            if bufs is None:
+                bufs = self._gathered[N] = (torch.empty((W * N, feats.shape[1]), dtype=torch.float32, device=self.device),
+                                            torch.empty((W * N, self.ldz), dtype=torch.float32, device=self.device))
+            feats_all, dz_all = bufs
+            if self.time_collective:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            # the features leave at once: their gather runs under the Dense forward and the loss
+            works.append(parallel.all_gather_rows(feats_all, feats, self.group, async_op=True))
+        # the local loss: into the bucket, or - gather mode - into the first padding column of dz's first row (the kernels
+        # write dz's padding, zeros, before the loss sum lands there; the weight gradient never reads it)
+        loss_slot = dz.view(-1)[m.units:m.units + 1] if gathers else self.bucket.loss
         part = ops.dense_splitk(feats, m.dense_wt, m.units, part=ws['part'])
         if self.fused_tail:
             # head activation, loss forward / backward and head Jacobian in one launch; y and dL/dy stay in LDS
-            ops.train_tail(part, m.dense_b, y_true, self.ldz, m.S, m.B, m.C, m.img_size, dz=dz, loss_out=self.bucket.loss)
+            ops.train_tail(part, m.dense_b, y_true, self.ldz, m.S, m.B, m.C, m.img_size, dz=dz, loss_out=loss_slot)
         else:
             y = ops.head_activate(part, m.dense_b, m.S, m.B, m.C, out=ws['y'])
-            _, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size, loss_out=self.bucket.loss)
+            _, _, grad = ops.yolo_loss_fwd_bwd(y_true, y, m.B, m.C, m.img_size, loss_out=loss_slot)
             ops.head_activate_bwd(y, grad, self.ldz, m.B, m.C, out=dz)
-        ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
+        if not gathers:
+            ops.dense_wgrad(dz, feats, m.units, self.dwt, self.db)
+            return self.bucket.loss
+        works.append(parallel.all_gather_rows(dz_all, dz, self.group, async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()                     # nccl: the current stream waits for the collective, the host goes on
+        if self.time_collective:
+            e1.record()
+            self.collective_events = (e0, e1)
+        ops.dense_wgrad(dz_all, feats_all, m.units, self.dwt, self.db)
+        # the group's loss: the ranks' local losses in rank order (the same on every rank)
+        torch.sum(dz_all.view(W, N * self.ldz)[:, m.units], dim=0, keepdim=True, out=self.bucket.loss)
         return self.bucket.loss
 
     def _take_features_back(self):
@@ -343,7 +391,7 @@ class Trainer:
     def _exchange_and_update(self, defer_adam=False, loss_out=None):
         """ONE all-reduce of the bucket, the global loss copied out (into loss_out (1,) if given), ONE Adam launch - on the
         current stream."""
-        if not self.skip_collective:
+        if not self.skip_collective and not self._gathers():      # ('gather': the exchange happened inside _tail)
             if self.time_collective:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

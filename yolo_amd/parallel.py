@@ -1,6 +1,7 @@
 """Data-parallel helpers: one process per GPU, torch.distributed ('nccl' == RCCL over xGMI on ROCm;
 'gloo' in the CPU tests).  The hot path shards by image, so inference needs no data-path
-collective; the only exchanges are (a) the SUM all-reduce of the Dense gradient in training and
+collective; the only exchanges are (a) the gradient exchange of the Dense layer in training - the SUM all-reduce of
+[dWt | db | loss] or, for equal shards, the all-gather of features and dz it can be computed from (engine.Trainer) - and
 (b) an optional all-gather of fixed-size detection records.  These helpers are
 device-agnostic on purpose: the same code runs under gloo with CPU tensors in tests/."""
 import torch
@@ -53,6 +54,19 @@ class GradBucket:
         if world(group)[1] == 1 and not self.always:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def all_gather_rows(out, inp, group=None, async_op=False):
+    """out (world * n, ...) <- every rank's inp (n, ...), in rank order (one all_gather_into_tensor: equal n on every rank).
+    -> the Work handle when async_op and the backend runs the collective asynchronously on the device ('nccl' = RCCL), else
+    None: the gloo rehearsal / test backend gathers device tensors through the host, synchronously."""
+    if inp.is_cuda and dist.get_backend(group) != 'nccl':
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+        return None
+    work = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+    return work if async_op else None
 
 
 RECORD_WIDTH = 6        # x0, y0, x1, y1, score, class (-1 where the slot is not kept)
