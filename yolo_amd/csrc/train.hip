@@ -31,14 +31,24 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float *__restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const bool uok0 = u0 + i < units, uok1 = u0 + 32 + i < units;
     const bool kok0 = k0 + i < K, kok1 = k0 + 32 + i < K;
+    // Operand fetch through buffer resources: the lane's part of the address (column, image parity) is a constant VGPR, the
+    // image pair is a SCALAR offset, rows past N and columns past units / K fall outside the resource and read as zero - no
+    // address arithmetic and no selects in the vector ALU, which the exact-f32 MFMA shares (conv_gemm.hip: every vector
+    // instruction between two MFMAs costs matrix cycles).  Matters when the loop is long: the gathered rows of a
+    // data-parallel group (Trainer.exchange = 'gather', 64 ... 512 rows); one rank's 32 rows are bound by the 73.8 MB store.
+    constexpr unsigned kOOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t dz_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dz), 0, (int)((long long)N * ldz * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((long long)N * K * 4), 0x00020000);
+    const unsigned va0 = uok0 ? (unsigned)(h * ldz + u0 + i) * 4u : kOOB, va1 = uok1 ? (unsigned)(h * ldz + u0 + 32 + i) * 4u : kOOB;
+    const unsigned vb0 = kok0 ? (unsigned)(h * K + k0 + i) * 4u : kOOB, vb1 = kok1 ? (unsigned)(h * K + k0 + 32 + i) * 4u : kOOB;
     float bsum0 = 0.f, bsum1 = 0.f;
-    for (int b = h; b < N + h; b += 2) {       // both half-waves run the same trip count
-        const bool bok = b < N;
-        const float *dzr = dz + (size_t)b * ldz + u0 + i;
-        const float *xr = x + (size_t)b * K + k0 + i;
-        const float a0 = (bok && uok0) ? dzr[0] : 0.f, a1 = (bok && uok1) ? dzr[32] : 0.f;
-        const float b0 = (bok && kok0) ? xr[0] : 0.f, b1 = (bok && kok1) ? xr[32] : 0.f;
-        bsum0 += a0;
+    for (int b = 0; b < N; b += 2) {                 // images b + h in the two half-waves
+        const int sa = b * ldz * 4, sb = b * K * 4;
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dz_rsrc, (int)va0, sa, 0));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dz_rsrc, (int)va1, sa, 0));
+        const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)vb0, sb, 0));
+        const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)vb1, sb, 0));
+        bsum0 += a0;                                 // (only the first column of workgroups uses them; a branch around the two adds measured slower)
         bsum1 += a1;
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
@@ -101,6 +111,7 @@ extern "C" int ty1_dense_wgrad_f32(const float *dz, const float *x, float *dwt, 
     TY1_REQUIRE(N >= 0 && K > 0 && units > 0, "ty1_dense_wgrad: bad dimensions");
     TY1_REQUIRE(dz && x && dwt && db, "ty1_dense_wgrad: null pointer");
     TY1_REQUIRE(ldk >= K && ldz >= units, "ty1_dense_wgrad: leading dimensions too small");
+    TY1_REQUIRE((long long)N * K * 4 < (1ll << 31) && (long long)N * ldz * 4 < (1ll << 31), "ty1_dense_wgrad: dz and x must stay below 2 GiB each (N=%d)", N);
     hipStream_t s = (hipStream_t)stream;
     ty1::ProfScope prof("dense_wgrad", s);
     dim3 grid((K + 127) / 128, (units + 127) / 128);
