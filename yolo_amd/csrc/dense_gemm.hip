@@ -56,16 +56,19 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
         const_cast<void *>(a.x), 0, (int)((long long)a.M * a.K * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void *>(a.w), 0, (int)((long long)a.units * a.ldk * ESZ), 0x00020000);
+    // per-thread part of a fetch address (row, 16-byte piece of the chunk); the chunk itself is a SCALAR offset: no vector
+    // arithmetic per load next to the MFMAs (conv_gemm.hip's rule; train.hip's weight-gradient loop gained 13-20 % from it)
+    const unsigned a_bytes = (unsigned)((long long)a.M * a.K * ESZ), b_bytes = (unsigned)((long long)a.units * a.ldk * ESZ);
     unsigned a_base[AP], b_base[BP];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         const int row = p * RPP + prow, m = mt * BM + row;
-        a_base[p] = (row < BM && m < a.M) ? (unsigned)((long long)m * a.K * ESZ) : kOOB;
+        a_base[p] = (row < BM && m < a.M) ? (unsigned)((long long)m * a.K * ESZ) + (unsigned)piece * 16u : kOOB;
     }
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
         const int row = p * RPP + prow, n = nt * BN + row;
-        b_base[p] = (row < BN && n < a.units) ? (unsigned)((long long)n * a.ldk * ESZ) : kOOB;
+        b_base[p] = (row < BN && n < a.units) ? (unsigned)((long long)n * a.ldk * ESZ) + (unsigned)piece * 16u : kOOB;
     }
     const int kc_begin = (int)((long long)a.chunks_total * split / a.splits);
     const int kc_end = (int)((long long)a.chunks_total * (split + 1) / a.splits);
@@ -73,15 +76,14 @@ __global__ __launch_bounds__(256) void dense_gemm_f32_kernel(const DenseArgs a) 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 ra[AP], rb[BP];
     int ld_kc = kc_begin;
-    auto load_chunk = [&]() {                 // past kc_end every lane goes out of range and nothing is fetched
+    auto load_chunk = [&]() {                 // past kc_end the scalar offset is the size of the operand: every lane out of range, nothing fetched
         const bool live = ld_kc < kc_end;
-        const unsigned koff = (unsigned)(ld_kc * BK + piece * 4) * 4u;
+        const unsigned koff = (unsigned)(ld_kc * BK) * 4u;
+        const int sa = (int)(live ? koff : a_bytes), sb = (int)(live ? koff : b_bytes);
 #pragma unroll
-        for (int p = 0; p < AP; ++p)
-            ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)((a_base[p] == kOOB || !live) ? kOOB : a_base[p] + koff), 0, 0);
+        for (int p = 0; p < AP; ++p) ra[p] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)a_base[p], sa, 0);
 #pragma unroll
-        for (int p = 0; p < BP; ++p)
-            rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)((b_base[p] == kOOB || !live) ? kOOB : b_base[p] + koff), 0, 0);
+        for (int p = 0; p < BP; ++p) rb[p] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (int)b_base[p], sb, 0);
         ++ld_kc;
     };
     auto store_chunk = [&](int buf) {
